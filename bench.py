@@ -1,0 +1,193 @@
+"""Headline benchmark: images/sec of the ViT-B/16 224 bf16 classification forward on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--config vit_b16]
+
+A "step" is one forward of the hot path (patch embedding -> 12 blocks -> final norm -> head) over one batch
+of synthetic images already resident in HBM.  With N > 1 (launched by torch.distributed.run, one rank per
+GPU) every rank runs its own replica on its own batch shard -- inference needs no collective -- and the
+reported value is all images of all ranks divided by the slowest rank's time (weak scaling).
+
+Rank 0 prints ONE JSON line.  ``roofline`` prices the dominant kernel, the LayerNorm-folded fc1 GEMM with the
+GELU epilogue (M = B*197, N = 3072, K = 768), by its algorithmic FLOPs per launch over its average launch
+duration, measured with events on the launch stream in an instrumented pass after the timed region.
+``cpu_baseline`` times the fp32 CPU oracle (a restatement of the reference's PyTorch forward) on a bounded
+sample of the same workload.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "vision-transformer_amd"), os.path.join(ROOT, "tests", "golden")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import torch  # noqa: E402
+import torch.nn as nn  # noqa: E402
+
+import weights as W  # noqa: E402
+
+PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA, MI355X
+PEAK_HBM_GBS = 8000.0
+
+
+def build_model(cfg, device, seed=0):
+    from vitm_amd.models import VisionTransformer, VITC
+    LN = nn.LayerNorm
+    vt = VisionTransformer(cfg["image_size"], patch_size=cfg["patch_size"], num_classes=cfg["num_classes"],
+                           num_heads=cfg["num_heads"], mlp_ratio=cfg["mlp_ratio"], depth=cfg["depth"],
+                           embed_dim=cfg["embed_dim"], norm_layer=LN,
+                           embed_norm_layer=LN if cfg["embed_norm"] else None,
+                           final_norm_layer=LN if cfg["final_norm"] else None)
+    m = VITC(vt).eval()
+    sd = {k: torch.from_numpy(v) for k, v in W.make_state_dict(cfg, seed).items()}
+    m.load_state_dict(sd, strict=True)
+    return m.to(device).to(torch.bfloat16), sd
+
+
+def cpu_baseline(cfg, sd, budget_s=15.0, batch=8):
+    """fp32 CPU oracle on `batch` images per pass, as many passes as fit the time budget (>= 2)."""
+    from oracle import vit_oracle as O
+    x = torch.from_numpy(W.make_input(cfg, batch, 7))
+    ocfg = W.oracle_cfg(cfg)
+    with torch.no_grad():
+        O.vitc_forward(x, sd, ocfg)  # warm-up
+        t0 = time.perf_counter()
+        n = 0
+        while True:
+            O.vitc_forward(x, sd, ocfg)
+            n += 1
+            dt = time.perf_counter() - t0
+            if (dt >= budget_s and n >= 2) or n >= 50:
+                break
+    return dict(value=round(n * batch / dt, 2), unit="images/sec", cores=torch.get_num_threads(), kind="port",
+                sample=f"{n} passes of batch {batch}, fp32 CPU oracle (torch {torch.__version__}), "
+                       f"{dt:.1f} s wall; same model and image size as the GPU workload")
+
+
+def fc1_kernel_time(model, x, steps):
+    """Average duration (ms) of the fc1 LN+GELU GEMM launches over `steps` forwards, by events on the launch
+    stream around each such launch."""
+    from vitm_amd import _ops
+    orig = _ops.gemm
+    pairs = []
+
+    def timed_gemm(A, pk, out, epilogue, M, **kw):
+        if epilogue != _ops.EPI_LN_GELU:
+            return orig(A, pk, out, epilogue, M, **kw)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r = orig(A, pk, out, epilogue, M, **kw)
+        e1.record()
+        pairs.append((e0, e1))
+        return r
+
+    _ops.gemm = timed_gemm
+    try:
+        with torch.no_grad():
+            for _ in range(steps):
+                model(x)
+        torch.cuda.synchronize()
+    finally:
+        _ops.gemm = orig
+    ms = [a.elapsed_time(b) for a, b in pairs]
+    return sum(ms) / len(ms), len(ms)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=256, help="images per GPU per step")
+    ap.add_argument("--config", default="vit_b16")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    cfg = W.CONFIGS[args.config]
+    shp = W.shapes(cfg)
+    from oracle.vit_oracle import flops_per_image
+    gflop_img = flops_per_image(shp) / 1e9
+
+    model, sd = build_model(cfg, dev)
+    g = torch.Generator(device="cpu").manual_seed(1234 + rank)
+    x = (torch.rand((args.batch, 3, cfg["image_size"], cfg["image_size"]), generator=g) * 2 - 1).to(dev).to(torch.bfloat16)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            model(x)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = model(x)
+        barrier()
+        elapsed = time.perf_counter() - t0
+    assert torch.isfinite(out.float()).all()
+
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    line = None
+    if rank == 0:
+        ms_step = elapsed / args.steps * 1e3
+        value = world * args.batch * args.steps / elapsed
+        fc1_ms, n_launch = fc1_kernel_time(model, x, max(2, min(args.steps, 10)))
+        M, N, K = args.batch * shp["tokens"], shp["hidden"], shp["embed_dim"]
+        fc1_tflops = 2.0 * M * N * K / (fc1_ms * 1e-3) / 1e12
+        model_tflops = value / world * gflop_img / 1e3
+        line = {
+            "metric": "images/sec, ViT-B/16 224px bf16 classification forward" if args.config == "vit_b16"
+                      else f"images/sec, {args.config} bf16 classification forward",
+            "value": round(value, 1), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_step, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"{args.config}: image {cfg['image_size']}, patch {cfg['patch_size']}, "
+                                   f"{shp['tokens']} tokens, dim {shp['embed_dim']}, depth {shp['depth']}, "
+                                   f"{shp['num_classes']} classes; classification forward (VITC)",
+                       "batch_per_gpu": args.batch, "global_batch": args.batch * world,
+                       "parallelism": f"batch-sharded replicas x{world}, no collective",
+                       "gflop_per_image": round(gflop_img, 3)},
+            "roofline": {"bound": "mfma", "achieved": round(fc1_tflops, 1), "peak": PEAK_BF16_TFLOPS,
+                         "unit": "TFLOP/s", "frac": round(fc1_tflops / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                         "kernel": "gemm_kernel<EPI_LN_GELU> (fc1: LayerNorm-folded GEMM + GELU)",
+                         "flops_per_launch": 2.0 * M * N * K, "avg_launch_ms": round(fc1_ms, 4),
+                         "launches_timed": n_launch},
+            "whole_forward": {"tflops_per_gpu": round(model_tflops, 1),
+                              "frac_of_bf16_peak": round(model_tflops / PEAK_BF16_TFLOPS, 4)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(cfg, sd)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if line is not None:
+        print(json.dumps(line), flush=True)
+
+
+if __name__ == "__main__":
+    main()

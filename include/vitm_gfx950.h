@@ -1,0 +1,145 @@
+/*
+ * libvitm_gfx950 -- C ABI of the MI355X (gfx950) forward path for the vitm Vision Transformer.
+ *
+ * The reference (MohitKumar020291/Vision-Transformer, package `vitm`) has no FFI of its own: its
+ * boundary is the Python nn.Module API of vitm/models/__init__.py:1-12.  These entry points are
+ * what a binding for that path calls, one per fused step of the forward; each comment names the
+ * reference code the step replaces.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer owned by the caller; the library never allocates or frees;
+ *  - matrices are row-major with an explicit leading dimension in ELEMENTS;
+ *  - activations are bf16 unless an `*_dtype` argument says otherwise; small per-channel vectors
+ *    (biases, LayerNorm affine, LayerScale, folded-LN sums) are fp32;
+ *  - calls are asynchronous on `stream` (a hipStream_t; NULL = the default stream) and run on
+ *    the calling thread's current HIP device; the library keeps no mutable global state;
+ *  - return 0 on success, a negative VITM_E* code otherwise; vitm_last_error() returns a
+ *    thread-local message for the last failure on the calling thread.
+ */
+#ifndef VITM_GFX950_H
+#define VITM_GFX950_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* vitm_stream_t; /* hipStream_t */
+
+enum vitm_dtype { VITM_BF16 = 0, VITM_F32 = 1 };
+
+enum vitm_status {
+  VITM_OK = 0,
+  VITM_EINVAL = -1,   /* bad argument (null pointer, unsupported size/alignment) */
+  VITM_ELAUNCH = -2,  /* the HIP runtime refused the launch */
+  VITM_EUNSUPPORTED = -3
+};
+
+/* Epilogues of vitm_gemm (acc = sum_k A[m,k] * Wp[n,k], fp32). */
+enum vitm_epilogue {
+  VITM_EPI_BIAS = 0,      /* out = acc + c[n]                                                  */
+  VITM_EPI_BIAS_GELU = 1, /* out = gelu_erf(acc + c[n])                                        */
+  VITM_EPI_LN = 2,        /* out = rstd[m] * (acc - mean[m] * s[n]) + c[n]    (LayerNorm folded) */
+  VITM_EPI_LN_GELU = 3,   /* out = gelu_erf(rstd[m] * (acc - mean[m] * s[n]) + c[n])            */
+  VITM_EPI_RESIDUAL = 4   /* out = resid[m,n] + g[n] * acc + c[n]   (bias + LayerScale + residual) */
+};
+
+const char* vitm_version(void);
+const char* vitm_last_error(void);
+
+/* K granularity the GEMM needs: packed weights and A operands have K padded to a multiple of this. */
+int vitm_gemm_k_multiple(void);
+
+/*
+ * One-time weight packing for a Linear / patch-projection layer, optionally folding the LayerNorm
+ * that precedes it and the LayerScale that follows it:
+ *   wp[n,k] = bf16(w[n,k] * ln_gamma[k])           k < K, zero for K <= k < kpad
+ *   s[n]    = sum_k float(wp[n,k])                 (only when s != NULL)
+ *   c[n]    = (sum_k ln_beta[k] * w[n,k] + bias[n]) * out_scale[n]
+ *   g[n]    = out_scale[n]                         (only when g != NULL)
+ * Null ln_gamma / ln_beta / bias / out_scale mean 1 / 0 / 0 / 1.  `w` is [N,K] row-major in
+ * `w_dtype` (nn.Linear.weight, or Conv2d.weight viewed as (D, C*ph*pw)); vectors are fp32.
+ * Replaces nothing at run time: it prepares nn.Linear weights (models.py:51,57,121,124),
+ * nn.LayerNorm affines (models.py:189,196) and LayerScale.gamma (models.py:135) for the fused GEMMs.
+ */
+int vitm_prepack_linear(const void* w, int w_dtype, const float* bias, const float* ln_gamma,
+                        const float* ln_beta, const float* out_scale, int N, int K, int kpad,
+                        void* wp, float* s, float* c, float* g, vitm_stream_t stream);
+
+/*
+ * Row statistics of LayerNorm: stats[m] = (mean, 1/sqrt(var + eps)) over x[m, 0:D], x bf16 or f32.
+ * First half of nn.LayerNorm (models.py:189,196,310,324); the affine half is folded into the
+ * consuming GEMM (VITM_EPI_LN*).
+ */
+int vitm_ln_stats(const void* x, int x_dtype, int64_t ldx, int M, int D, float eps, float* stats,
+                  vitm_stream_t stream);
+
+/*
+ * out[M,N] = epilogue(A[M,K] . Wp[N,K]^T).  A and Wp are bf16, K a multiple of
+ * vitm_gemm_k_multiple() (pad columns of A must be finite, pad columns of Wp zero), N a multiple
+ * of 8.  `stats` is [M][2] (VITM_EPI_LN*), `s`,`c`,`g` are [N] fp32, `resid` is bf16 [M,ldr]
+ * and may alias `out` (VITM_EPI_RESIDUAL).  `out_dtype` is VITM_BF16 or VITM_F32.
+ * When row_group > 0 output row m goes to row m + m / row_group + 1 (token rows of a (B, 1+Np, D)
+ * buffer, leaving row 0 of every image for the class token).
+ * Replaces nn.Linear in Attention.forward (models.py:76,94), MLP.forward with its GELU
+ * (models.py:126-130), LayerScale + the residual adds of Block.forward (models.py:209-210) and the
+ * classifier head (classifier.py:38).
+ */
+int vitm_gemm(const void* A, int64_t lda, const void* Wp, int64_t ldw, void* out, int64_t ldo,
+              int out_dtype, int M, int N, int K, int epilogue, const float* stats, const float* s,
+              const float* c, const float* g, const void* resid, int64_t ldr, int row_group,
+              vitm_stream_t stream);
+
+/*
+ * Patch embedding as an im2col-fused GEMM: tokens[b, 1 + py*gw + px, :] =
+ *   sum_{c,ky,kx} img[b,c,py*ph+ky,px*pw+kx] * Wp[:, (c,ky,kx)] + c[:]
+ * img is NCHW (bf16 or f32) contiguous, Wp is the packed (D, kpad) projection weight.  With
+ * cls_slot = 1 the output buffer is (B, 1+Np, D) and row 0 of each image is left untouched;
+ * with cls_slot = 0 it is (B, Np, D).
+ * Replaces PatchEmbed.forward's Conv2d + flatten + transpose (patch_embeddings.py:115-117).
+ */
+int vitm_patch_embed(const void* img, int img_dtype, int B, int C, int H, int W, int ph, int pw,
+                     const void* Wp, int64_t ldw, int kpad, const float* c, void* tokens,
+                     int64_t ldo, int D, int cls_slot, vitm_stream_t stream);
+
+/*
+ * In place on x (B, 1+Np, D) bf16: row 0 <- class token; token rows optionally LayerNorm'ed with
+ * (en_w,en_b) (PatchEmbed.norm_layer); then every row optionally LayerNorm'ed with (np_w,np_b)
+ * (norm_pre), then + pos[n,:].  Null pointers skip the step.
+ * Replaces patch_embeddings.py:120 and VisionTransformer.forward_features (models.py:356-360).
+ */
+int vitm_embed_finalize(void* x, int64_t ldx, int B, int ntok, int D, const float* cls,
+                        const float* pos, const float* en_w, const float* en_b, float en_eps,
+                        const float* np_w, const float* np_b, float np_eps, vitm_stream_t stream);
+
+/*
+ * Fused multi-head self-attention on a packed qkv activation: qkv is (B*N, 3*D) bf16 laid out as
+ * nn.Linear(dim, 3*dim) writes it ([q | k | v], each D = H*hd wide, head-major inside), out is
+ * (B*N, D) bf16 token-major:  out = softmax(scale * q k^T) v  per (image, head).
+ * head_dim must be 32, 64, 96 or 128.
+ * Replaces models.py:79-93 (reshape/permute, q*scale, q@k^T, softmax, @v, transpose/reshape).
+ */
+int vitm_attention(const void* qkv, int64_t ldqkv, void* out, int64_t ldo, int B, int N, int H,
+                   int head_dim, float scale, vitm_stream_t stream);
+
+/*
+ * Full LayerNorm: out[m,:] = (x[m,:] - mean) * rstd * w + b over D; x bf16, out bf16 or f32.
+ * Replaces norm_final (models.py:410) and PatchEmbed.norm_layer when used stand-alone.
+ */
+int vitm_layernorm(const void* x, int64_t ldx, void* out, int out_dtype, int64_t ldo, int M, int D,
+                   const float* w, const float* b, float eps, vitm_stream_t stream);
+
+/* out[m,n] = x[m,n] * gamma[n]  (LayerScale.forward stand-alone, models.py:138-139); bf16. */
+int vitm_scale_channels(const void* x, int64_t ldx, void* out, int64_t ldo, int M, int D,
+                        const float* gamma, vitm_stream_t stream);
+
+/* dst (bf16) <- src (f32), n elements; used to bring fp32 images/activations onto the bf16 path. */
+int vitm_cast_f32_to_bf16(const float* src, void* dst, int64_t n, vitm_stream_t stream);
+/* dst (f32) <- src (bf16), n elements. */
+int vitm_cast_bf16_to_f32(const void* src, float* dst, int64_t n, vitm_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VITM_GFX950_H */

@@ -72,6 +72,10 @@ def gen(name: str, batch: int, seed: int, depth=None, keep_stages=True, emb_rows
     stages, emb, logits = run_reference(model, x)
     out = dict(logits=logits.numpy(), batch=np.int64(batch), seed=np.int64(seed),
                depth=np.int64(cfg["depth"] if depth is None else depth))
+    # the reference's OWN bf16 forward (module.bfloat16(), bf16 input) on the same weights: how far a bf16
+    # forward of this network lands from the fp32 one, as a yardstick for the HIP bf16 path
+    _, _, logits_bf16 = run_reference(model.bfloat16(), x.bfloat16())
+    out["logits_ref_bf16"] = logits_bf16.float().numpy()
     if emb_rows is None:
         out["embeddings"] = emb.numpy()
     else:  # large configs: keep the cls row and a strided sample of token rows
@@ -84,7 +88,8 @@ def gen(name: str, batch: int, seed: int, depth=None, keep_stages=True, emb_rows
     path = os.path.join(HERE, f"{name}.npz")
     np.savez_compressed(path, **out)
     print(f"{name}: wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB), "
-          f"logits[0,:4]={logits[0, :4].tolist()}")
+          f"max|logit|={logits.abs().max():.3f}, reference bf16-vs-fp32 logit err "
+          f"{(logits_bf16.float() - logits).abs().max():.4f}")
 
 
 if __name__ == "__main__":

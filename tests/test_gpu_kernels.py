@@ -1,0 +1,237 @@
+"""Per-kernel parity on a real MI355X: each C-ABI entry point against a plain fp32 PyTorch statement of the
+same op on the same (bf16-rounded) inputs.
+
+Tolerances.  Outputs are bf16 (relative spacing 2^-8 = 3.9e-3) of an fp32-accumulated result, so the bar is
+|got - ref| <= 1e-2 * max|ref| for GEMM-shaped results (half an ulp of the largest output, plus slack for the
+reference's own rounding) and 2e-2 absolute for O(1) normalised outputs.  fp32 outputs: 1e-4 relative.
+"""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from vitm_amd import _ops
+    return _ops
+
+
+def _bf(x):
+    return x.to(torch.bfloat16)
+
+
+def _close(got, ref, rel=1e-2, what=""):
+    got, ref = got.float(), ref.float()
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    assert torch.isfinite(got).all(), f"{what}: non-finite output"
+    err = (got - ref).abs().max().item()
+    scale = max(ref.abs().max().item(), 1e-6)
+    assert err <= rel * scale, f"{what}: max err {err:.4g} vs scale {scale:.4g} (rel {err / scale:.3g} > {rel})"
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(DEV)
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 256, 256), (200, 136, 128), (1, 8, 64),
+                                   (197 * 3, 768, 768), (1000, 2304, 768), (333, 616, 192)])
+def test_gemm_bias(ops, M, N, K):
+    A = _bf(_rand(M, K, seed=1))
+    W = _rand(N, K, seed=2, scale=K ** -0.5)
+    b = _rand(N, seed=3)
+    pk = ops.pack_linear(W, b)
+    assert pk.kpad == K and pk.npad == N
+    out = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+    ops.gemm(A, pk, out, ops.EPI_BIAS, M)
+    ref = A.float() @ _bf(W).float().t() + b
+    _close(out, ref, what="gemm bias")
+
+
+def test_gemm_identity_asymmetric(ops):
+    """A = I against an asymmetric W catches a transposed / permuted fragment map exactly."""
+    K = N = 128
+    A = _bf(torch.eye(K, device=DEV))
+    W = (torch.arange(N, device=DEV).float()[:, None] * 0.5 + torch.arange(K, device=DEV).float()[None, :] * 0.0078125)
+    pk = ops.pack_linear(W, None)
+    out = torch.empty((K, N), dtype=torch.float32, device=DEV)
+    ops.gemm(A, pk, out, ops.EPI_BIAS, K)
+    ref = _bf(W).float().t()
+    assert torch.equal(out, ref)
+
+
+def test_gemm_k_padding_and_f32_out(ops):
+    M, N, K = 77, 10, 100  # K -> 128, N -> 16
+    A = torch.zeros((M, 128), dtype=torch.bfloat16, device=DEV)
+    A[:, :K] = _bf(_rand(M, K, seed=4))
+    W, b = _rand(N, K, seed=5, scale=0.1), _rand(N, seed=6)
+    pk = ops.pack_linear(W, b)
+    assert (pk.kpad, pk.npad) == (128, 16)
+    out = torch.empty((M, 16), dtype=torch.float32, device=DEV)
+    ops.gemm(A, pk, out, ops.EPI_BIAS, M)
+    ref = A[:, :K].float() @ _bf(W).float().t() + b
+    _close(out[:, :N], ref, rel=1e-4, what="gemm f32 out")
+    assert (out[:, N:] == 0).all()
+
+
+@pytest.mark.parametrize("gelu", [False, True])
+@pytest.mark.parametrize("M,N,D", [(197 * 2, 2304, 768), (130, 512, 128), (65, 192 * 3, 192)])
+def test_gemm_layernorm_folded(ops, M, N, D, gelu):
+    x = _bf(_rand(M, D, seed=7) * 1.5 + 0.3)
+    W, b = _rand(N, D, seed=8, scale=D ** -0.5), _rand(N, seed=9, scale=0.1)
+    lw, lb = 1.0 + 0.1 * _rand(D, seed=10), 0.1 * _rand(D, seed=11)
+    pk = ops.pack_linear(W, b, lw, lb)
+    stats = ops.ln_stats(x, M, D, 1e-5)
+    out = torch.empty((M, N), dtype=torch.bfloat16, device=DEV)
+    ops.gemm(x, pk, out, ops.EPI_LN_GELU if gelu else ops.EPI_LN, M, stats=stats)
+    xn = torch.nn.functional.layer_norm(x.float(), (D,), lw, lb, 1e-5)
+    ref = xn @ W.t() + b
+    if gelu:
+        ref = torch.nn.functional.gelu(ref)
+    # the folded form rounds W*gamma (not LN(x)) to bf16: same error class as a bf16 linear
+    _close(out, ref, rel=1.5e-2, what="ln-folded gemm")
+
+
+def test_ln_stats(ops):
+    M, D = 300, 768
+    x = _bf(_rand(M, D, seed=12) * 2 + 5.0)
+    st = ops.ln_stats(x, M, D, 1e-5)
+    xf = x.float()
+    mean = xf.mean(-1)
+    rstd = 1.0 / torch.sqrt(xf.var(-1, unbiased=False) + 1e-5)
+    _close(st[:, 0], mean, rel=1e-5, what="mean")
+    _close(st[:, 1], rstd, rel=1e-4, what="rstd")
+
+
+@pytest.mark.parametrize("M,N,K", [(197 * 2, 768, 3072), (100, 128, 512), (50, 192, 768)])
+def test_gemm_residual_layerscale_inplace(ops, M, N, K):
+    A = _bf(_rand(M, K, seed=13))
+    W, b = _rand(N, K, seed=14, scale=K ** -0.5), _rand(N, seed=15, scale=0.1)
+    gamma = 1.0 + 0.1 * _rand(N, seed=16)
+    x = _bf(_rand(M, N, seed=17))
+    ref = x.float() + gamma * (A.float() @ _bf(W).float().t() + b)
+    pk = ops.pack_linear(W, b, out_scale=gamma)
+    ops.gemm(A, pk, x, ops.EPI_RESIDUAL, M, resid=x)  # in place on the residual stream
+    _close(x, ref, what="residual gemm")
+
+
+def test_gelu_epilogue_matches_erf_gelu(ops):
+    M, N, K = 128, 128, 64
+    A = _bf(_rand(M, K, seed=18) * 2)
+    W = _rand(N, K, seed=19, scale=0.3)
+    pk = ops.pack_linear(W, None)
+    out = torch.empty((M, N), dtype=torch.bfloat16, device=DEV)
+    ops.gemm(A, pk, out, ops.EPI_BIAS_GELU, M)
+    ref = torch.nn.functional.gelu(A.float() @ _bf(W).float().t())
+    _close(out, ref, what="gelu")
+
+
+def _attn_ref(qkv, B, N, H, hd):
+    D = H * hd
+    q, k, v = qkv.float().reshape(B, N, 3, H, hd).permute(2, 0, 3, 1, 4)
+    s = (q * hd ** -0.5) @ k.transpose(-2, -1)
+    return (s.softmax(-1) @ v).transpose(1, 2).reshape(B * N, D)
+
+
+@pytest.mark.parametrize("B,N,H,hd", [(2, 197, 3, 64), (1, 65, 2, 64), (1, 577, 2, 64), (3, 32, 1, 64),
+                                      (2, 1, 2, 64), (1, 65, 2, 96), (1, 197, 2, 32), (1, 100, 1, 128),
+                                      (1, 300, 1, 64)])
+def test_attention(ops, B, N, H, hd):
+    D = H * hd
+    qkv = _bf(_rand(B * N, 3 * D, seed=20) * 1.5)
+    out = torch.full((B * N, D), float("nan"), dtype=torch.bfloat16, device=DEV)
+    ops.attention(qkv, out, B, N, H, hd, hd ** -0.5)
+    _close(out, _attn_ref(qkv, B, N, H, hd), rel=1.5e-2, what="attention")
+
+
+def test_attention_online_softmax_rescale(ops):
+    """A late key far above all earlier scores forces the running-max rescale branch in every tile order."""
+    B, N, H, hd = 1, 197, 1, 64
+    qkv = _bf(_rand(B * N, 3 * hd, seed=21))
+    q = qkv[:, :hd].float()
+    for key_row in (5, 100, 196):  # first tile, middle tile, ragged last tile
+        t = qkv.clone()
+        t[key_row, hd:2 * hd] = _bf(q[7] * 6.0)  # k[key_row] aligned with q[7]: its score dominates row 7
+        out = torch.empty((N, hd), dtype=torch.bfloat16, device=DEV)
+        ops.attention(t, out, B, N, H, hd, hd ** -0.5)
+        _close(out, _attn_ref(t, B, N, H, hd), rel=1.5e-2, what=f"attention spike at key {key_row}")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("img,p,D,B", [(224, 16, 768, 2), (32, 4, 192, 3), (32, 8, 128, 2), (28, 14, 64, 1)])
+def test_patch_embed(ops, img, p, D, B, dtype):
+    from oracle import vit_oracle as O
+    x = (_rand(B, 3, img, img, seed=22)).to(dtype)
+    w = _rand(D, 3, p, p, seed=23, scale=(3 * p * p) ** -0.5)
+    b = _rand(D, seed=24, scale=0.1)
+    pk = ops.pack_linear(w, b)
+    g = img // p
+    Np = g * g
+    for cls_slot in (False, True):
+        rows = B * (Np + int(cls_slot))
+        tok = torch.full((rows, D), 7.0, dtype=torch.bfloat16, device=DEV)
+        ops.patch_embed(x, pk, tok, (p, p), D, cls_slot)
+        cols = O.im2col(x.float().cpu(), (p, p)).to(DEV)
+        ref = cols @ _bf(w).float().reshape(D, -1).t() + b
+        got = tok.view(B, Np + int(cls_slot), D)
+        if cls_slot:
+            assert (got[:, 0] == 7.0).all(), "class-token slot must be left untouched"
+            got = got[:, 1:]
+        # fp32 images are rounded to bf16 on the way into the MFMA
+        ref_in = O.im2col(x.to(torch.bfloat16).float().cpu(), (p, p)).to(DEV) @ _bf(w).float().reshape(D, -1).t() + b
+        _close(got, ref_in, what="patch embed")
+
+
+def test_embed_finalize_and_layernorm(ops):
+    B, N, D = 3, 65, 192
+    tok = _bf(_rand(B * N, D, seed=25))
+    cls, pos = _rand(D, seed=26), _rand(N, D, seed=27)
+    ew, eb = 1 + 0.1 * _rand(D, seed=28), 0.1 * _rand(D, seed=29)
+    nw, nb = 1 + 0.1 * _rand(D, seed=30), 0.1 * _rand(D, seed=31)
+    x = tok.clone()
+    ops.embed_finalize(x, B, N, D, cls, pos, ew, eb, 1e-5, nw, nb, 1e-5)
+    F = torch.nn.functional
+    t = tok.float().view(B, N, D).clone()
+    t[:, 1:] = F.layer_norm(t[:, 1:], (D,), ew, eb, 1e-5)
+    t[:, 0] = cls
+    ref = F.layer_norm(t, (D,), nw, nb, 1e-5) + pos
+    _close(x.view(B, N, D), ref, rel=6e-3, what="embed_finalize")
+    # pos only
+    x = tok.clone()
+    ops.embed_finalize(x, B, N, D, cls, pos, None, None, 0.0, None, None, 0.0)
+    t = tok.float().view(B, N, D).clone()
+    t[:, 0] = cls
+    _close(x.view(B, N, D), t + pos, rel=6e-3, what="embed_finalize (no norms)")
+    # full layernorm, bf16 and fp32 out
+    for dt, rel in ((torch.bfloat16, 6e-3), (torch.float32, 1e-5)):
+        out = torch.empty((B * N, D), dtype=dt, device=DEV)
+        ops.layernorm(tok, out, B * N, D, nw, nb, 1e-5)
+        _close(out, F.layer_norm(tok.float(), (D,), nw, nb, 1e-5), rel=rel, what=f"layernorm {dt}")
+
+
+def test_scale_and_casts(ops):
+    M, D = 50, 136
+    x = _rand(M, D, seed=32)
+    xb = ops.to_bf16(x)
+    assert torch.equal(xb, x.to(torch.bfloat16))
+    assert torch.equal(ops.to_f32(xb), xb.float())
+    g = _rand(D, seed=33)
+    out = torch.empty_like(xb)
+    ops.scale_channels(xb, out, M, D, g)
+    _close(out, xb.float() * g, rel=5e-3, what="scale")
+
+
+def test_bad_arguments_report_errors(ops):
+    from vitm_amd import VitmError
+    A = torch.zeros((8, 100), dtype=torch.bfloat16, device=DEV)
+    pk = ops.pack_linear(torch.zeros((8, 64), device=DEV), None)
+    with pytest.raises((VitmError, AssertionError)):
+        ops.gemm(A[:, :32], pk, torch.empty((8, 8), dtype=torch.bfloat16, device=DEV), ops.EPI_BIAS, 8)
+    with pytest.raises(VitmError):
+        ops.attention(torch.zeros((4, 3 * 48), dtype=torch.bfloat16, device=DEV),
+                      torch.zeros((4, 48), dtype=torch.bfloat16, device=DEV), 1, 4, 1, 48, 0.1)

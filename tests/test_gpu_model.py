@@ -1,0 +1,173 @@
+"""End-to-end parity of the HIP forward on a real MI355X.
+
+Against (a) the golden fixtures captured from the imported reference and (b) the CPU oracle on the same
+seeded inputs.  Tolerances for the bf16 path follow BASELINE.json's north star -- logits within 2e-2 max-abs
+and embedding cosine >= 0.999 per token row -- with the logit bar made scale-aware: 2e-2 * max(1, max|logit|).
+The synthetic "trained-like" weights give logits up to |3.6|, where one bf16 ulp is already 1.6e-2, and the
+reference's OWN bf16 forward (module.bfloat16() on the CPU, stored in the fixtures as ``logits_ref_bf16``)
+lands 2.2e-2 .. 4.4e-2 from its fp32 forward on these networks; so a second check requires the HIP path to be
+no further from the fp32 reference than 1.5x the reference's own bf16 forward is.
+Stage-level checks use 3e-2 of the tensor's max magnitude.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+import weights as W
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+LOGIT_TOL = 2e-2
+COS_MIN = 0.999
+
+
+def build(name, seed, depth=None, device="cuda", dtype=torch.bfloat16):
+    from vitm_amd.models import VisionTransformer, VITC
+    cfg = W.CONFIGS[name]
+    LN = nn.LayerNorm
+    vt = VisionTransformer(cfg["image_size"], patch_size=cfg["patch_size"], num_classes=cfg["num_classes"],
+                           num_heads=cfg["num_heads"], mlp_ratio=cfg["mlp_ratio"],
+                           depth=cfg["depth"] if depth is None else depth, embed_dim=cfg["embed_dim"],
+                           norm_layer=LN, embed_norm_layer=LN if cfg["embed_norm"] else None,
+                           final_norm_layer=LN if cfg["final_norm"] else None)
+    m = VITC(vt).eval()
+    sd = {k: torch.from_numpy(v) for k, v in W.make_state_dict(cfg, seed, depth).items()}
+    m.load_state_dict(sd, strict=True)
+    return m.to(device=device, dtype=dtype), sd, cfg
+
+
+def logit_tol(ref_logits):
+    return LOGIT_TOL * max(1.0, ref_logits.abs().max().item())
+
+
+def cos_rows(a, b):
+    a, b = a.double().reshape(-1, a.shape[-1]), b.double().reshape(-1, b.shape[-1])
+    return torch.nn.functional.cosine_similarity(a, b, dim=-1).min().item()
+
+
+def rel_err(a, b):
+    a, b = a.double(), b.double()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-12)).item()
+
+
+@pytest.mark.parametrize("name", ["tiny2", "vit_tiny_cifar", "vit_s16", "vit_b16", "vit_b16_384"])
+@pytest.mark.parametrize("in_dtype", [torch.bfloat16, torch.float32])
+def test_model_matches_reference_golden(name, in_dtype):
+    if in_dtype == torch.float32 and name not in ("tiny2", "vit_b16"):
+        pytest.skip("fp32-input variant checked on two configs")
+    g = np.load(os.path.join(GOLD, f"{name}.npz"))
+    seed, batch = int(g["seed"]), int(g["batch"])
+    model, sd, cfg = build(name, seed)
+    x = torch.from_numpy(W.make_input(cfg, batch, seed + 1)).cuda().to(in_dtype)
+    with torch.no_grad():
+        logits = model(x)
+        emb = model.vit_model(x)
+    assert logits.dtype == in_dtype and emb.dtype == in_dtype
+    assert logits.shape == (batch, cfg["num_classes"])
+    ref_logits = torch.from_numpy(g["logits"])
+    err = (logits.float().cpu() - ref_logits).abs().max().item()
+    assert err <= logit_tol(ref_logits), f"{name}: logits max-abs err {err:.4g}"
+    yard = (torch.from_numpy(g["logits_ref_bf16"]) - ref_logits).abs().max().item()
+    assert err <= 1.5 * yard, f"{name}: logits err {err:.4g} vs the reference's own bf16 forward {yard:.4g}"
+    ref_emb = torch.from_numpy(g["embeddings"])
+    got_emb = emb.float().cpu()
+    if "embeddings_rows" in g:
+        got_emb = got_emb[:, torch.from_numpy(g["embeddings_rows"])]
+    c = cos_rows(got_emb, ref_emb)
+    assert c >= COS_MIN, f"{name}: min embedding cosine {c:.6f}"
+
+
+def test_stages_match_oracle():
+    """forward_features, every block and the final norm against the CPU oracle (tiny2: all optional norms on)."""
+    from oracle import vit_oracle as O
+    model, sd, cfg = build("tiny2", seed=0)
+    x = torch.from_numpy(W.make_input(cfg, 3, 42))
+    stages = []
+    ref_emb = O.vit_forward(x, sd, W.oracle_cfg(cfg), "vit_model.", torch.float32, stages)
+    vt = model.vit_model
+    with torch.no_grad():
+        xb = x.cuda().to(torch.bfloat16)
+        f = vt.forward_features(xb)
+        assert rel_err(f.float().cpu(), stages[0]) < 2e-2
+        h = f
+        for i, blk in enumerate(vt.blocks):
+            h = blk(h)
+            assert rel_err(h.float().cpu(), stages[i + 1]) < 3e-2, f"block {i}"
+        emb = vt.forward_heads(f)
+        assert cos_rows(emb.float().cpu(), ref_emb) >= COS_MIN
+        assert rel_err(emb.float().cpu(), ref_emb) < 3e-2
+
+
+def test_reference_shape_contracts():
+    """The shape assertions of the reference's own tests (tests/test_block.py:13-16,
+    tests/test_patch_embed.py:18-21,29-32,39-42, tests/test_vitc.py:34) on the HIP path."""
+    from vitm_amd.models import PatchEmbed, VisionTransformer, VITC
+    from vitm_amd.models.models import Block
+    block = Block(dim=768, num_heads=12, mlp_ratio=4.0).cuda()
+    x = torch.randn(8, 197, 768, device="cuda")
+    assert block(x).shape == x.shape
+    pe = PatchEmbed(patch_size=8, in_channels=3, embed_dim=768).cuda()
+    assert pe(torch.randn(1, 3, 224, 224, device="cuda")).shape == torch.Size([1, 784, 768])
+    pe = PatchEmbed(image_size=32, patch_size=8, in_channels=3, embed_dim=32, flatten=False).cuda()
+    assert pe(torch.randn(1, 3, 32, 32, device="cuda")).shape == torch.Size([1, 32, 4, 4])
+    pe = PatchEmbed(image_size=32, patch_size=8).cuda()
+    with pytest.raises(AssertionError):
+        pe(torch.randn(1, 3, 30, 30, device="cuda"))
+    # the reference's CIFAR recipe (training/train.py:167-175): head_dim 96, hidden 614
+    LN = nn.LayerNorm
+    vt = VisionTransformer(32, patch_size=4, num_classes=10, num_heads=8, mlp_ratio=0.8, norm_layer=LN,
+                           embed_norm_layer=LN, final_norm_layer=LN, depth=2)
+    vitc = VITC(vit_model=vt).cuda()
+    out = vitc(torch.randn(8, 3, 32, 32, device="cuda"))
+    assert out.shape == torch.Size((8, 10))
+
+
+def test_cifar_recipe_matches_reference_golden():
+    """head_dim 96 and a hidden width (614) that needs N/K padding."""
+    g = np.load(os.path.join(GOLD, "cifar_recipe.npz"))
+    model, sd, cfg = build("cifar_recipe", int(g["seed"]))
+    x = torch.from_numpy(W.make_input(cfg, int(g["batch"]), int(g["seed"]) + 1)).cuda().to(torch.bfloat16)
+    with torch.no_grad():
+        logits = model(x)
+        emb = model.vit_model(x)
+    ref = torch.from_numpy(g["logits"])
+    assert (logits.float().cpu() - ref).abs().max().item() <= logit_tol(ref)
+    assert cos_rows(emb.float().cpu(), torch.from_numpy(g["embeddings"])) >= COS_MIN
+
+
+def test_standalone_modules_match_torch():
+    from vitm_amd.models.models import Attention, MLP, LayerScale
+    torch.manual_seed(0)
+    F = torch.nn.functional
+    x = torch.randn(2, 197, 384, device="cuda")
+    xb = x.to(torch.bfloat16).float()
+    attn = Attention(384, num_heads=6, qkv_bias=True).cuda()
+    with torch.no_grad():
+        attn.qkv.weight.mul_(3.0)
+        attn.qkv.bias.normal_(0, 0.1)
+        qkv = F.linear(xb, attn.qkv.weight, attn.qkv.bias).reshape(2, 197, 3, 6, 64).permute(2, 0, 3, 1, 4)
+        s = (qkv[0] * 64 ** -0.5) @ qkv[1].transpose(-2, -1)
+        ref = F.linear((s.softmax(-1) @ qkv[2]).transpose(1, 2).reshape(2, 197, 384), attn.proj.weight, attn.proj.bias)
+        assert rel_err(attn(x).cpu(), ref.cpu()) < 3e-2
+        mlp = MLP(384, 1536, bias=True).cuda()
+        ref = mlp.linear_layer2(F.gelu(mlp.linear_layer1(xb)))
+        assert rel_err(mlp(x).cpu(), ref.cpu()) < 3e-2
+        ls = LayerScale(384, init_values=0.5).cuda()
+        assert rel_err(ls(x).cpu(), (xb * 0.5).cpu()) < 1e-2
+
+
+def test_batch_independence_and_determinism():
+    """Images are independent: a batch equals its halves run separately (the multi-GPU sharding invariant),
+    and two runs are bit-identical."""
+    model, sd, cfg = build("vit_tiny_cifar", seed=5)
+    x = torch.from_numpy(W.make_input(cfg, 8, 99)).cuda().to(torch.bfloat16)
+    with torch.no_grad():
+        full = model(x)
+        again = model(x)
+        halves = torch.cat([model(x[:3]), model(x[3:])])
+    assert torch.equal(full, again)
+    assert torch.equal(full, halves)

@@ -1,0 +1,17 @@
+// Version and thread-local error reporting of libvitm_gfx950.
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "../../include/vitm_gfx950.h"
+
+static thread_local char g_err[512] = "";
+
+void vitm_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" const char* vitm_version(void) { return "vitm_gfx950 0.1.0 (gfx950, bf16 MFMA)"; }
+extern "C" const char* vitm_last_error(void) { return g_err; }

@@ -1,0 +1,74 @@
+// Shared device helpers and host-side error plumbing for libvitm_gfx950 (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "../../include/vitm_gfx950.h"
+
+typedef unsigned short bf16_t;  // raw bf16 bits
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;   // MFMA A/B operand (4 VGPRs)
+typedef __attribute__((ext_vector_type(8))) unsigned short u16x8_t;
+typedef __attribute__((ext_vector_type(4))) unsigned short u16x4_t;
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+
+#define GPTR(p) ((const void __attribute__((address_space(1)))*)(p))
+#define LPTR(p) ((void __attribute__((address_space(3)))*)(p))
+
+__device__ __forceinline__ float bf2f(bf16_t u) {
+  return __builtin_bit_cast(float, (unsigned)u << 16);
+}
+// round-to-nearest-even, NaN-preserving (hipcc lowers the cast to v_cvt_pk_bf16_f32)
+__device__ __forceinline__ bf16_t f2bf(float f) {
+  return __builtin_bit_cast(bf16_t, (__bf16)f);
+}
+__device__ __forceinline__ unsigned pack_bf2(float lo, float hi) {
+  return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// erf by Abramowitz & Stegun 7.1.26 (|abs err| <= 1.5e-7), enough for fp32-tolerance GELU and far
+// cheaper in an MFMA epilogue than the libm polynomial.
+__device__ __forceinline__ float erf_as(float x) {
+  const float ax = fabsf(x);
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  p *= t;
+  const float e = __builtin_amdgcn_exp2f(-ax * ax * 1.4426950408889634f);
+  const float r = fmaf(-p, e, 1.0f);
+  return copysignf(r, x);
+}
+__device__ __forceinline__ float gelu_erf(float v) {
+  return 0.5f * v * (1.0f + erf_as(v * 0.70710678118654752f));
+}
+
+// ---- host side ------------------------------------------------------------------------------
+void vitm_set_error(const char* fmt, ...);
+
+#define VITM_REQUIRE(cond, ...)            \
+  do {                                     \
+    if (!(cond)) {                         \
+      vitm_set_error(__VA_ARGS__);         \
+      return VITM_EINVAL;                  \
+    }                                      \
+  } while (0)
+
+#define VITM_CHECK_LAUNCH(name)                                                   \
+  do {                                                                            \
+    hipError_t e__ = hipGetLastError();                                           \
+    if (e__ != hipSuccess) {                                                      \
+      vitm_set_error("%s: launch failed: %s", name, hipGetErrorString(e__));      \
+      return VITM_ELAUNCH;                                                        \
+    }                                                                             \
+  } while (0)

@@ -1,0 +1,361 @@
+// Row-wise (HBM-bound) kernels of the ViT forward for gfx950, one 64-lane wave per row, 16-byte loads:
+//   ln_stats        (mean, rstd) per row -- the statistics half of a LayerNorm folded into the next GEMM
+//   layernorm       full LayerNorm (final norm / stand-alone)
+//   embed_finalize  class-token row, optional patch norm, norm_pre, + positional embedding, in place
+//   scale_channels  LayerScale stand-alone
+//   prepack_linear  one-time weight packing (LayerNorm / LayerScale folding, bf16, K padding)
+//   casts           f32 <-> bf16
+// A row is held in registers (up to 4 chunks of 8 values per lane, D <= 2048) so mean and variance are
+// the exact two-pass form over one read of the row.
+#include "common.h"
+
+namespace {
+
+constexpr int MAXC = 4;               // 8-element chunks per lane
+constexpr int MAXD = 64 * 8 * MAXC;   // 2048
+constexpr int ROWS_PER_WG = 4;        // 256 threads
+
+struct Row {
+  float v[MAXC][8];
+};
+
+template <typename T>
+__device__ __forceinline__ void load8(const T* p, float* v);
+template <>
+__device__ __forceinline__ void load8<bf16_t>(const bf16_t* p, float* v) {
+  const u16x8_t u = *(const u16x8_t*)p;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = bf2f(u[e]);
+}
+template <>
+__device__ __forceinline__ void load8<float>(const float* p, float* v) {
+  const float4 a = *(const float4*)p, b = *(const float4*)(p + 4);
+  v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+  v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+__device__ __forceinline__ void store8(bf16_t* p, const float* v) {
+  uint4 o;
+  o.x = pack_bf2(v[0], v[1]); o.y = pack_bf2(v[2], v[3]);
+  o.z = pack_bf2(v[4], v[5]); o.w = pack_bf2(v[6], v[7]);
+  *(uint4*)p = o;
+}
+__device__ __forceinline__ void store8(float* p, const float* v) {
+  *(float4*)p = make_float4(v[0], v[1], v[2], v[3]);
+  *(float4*)(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+}
+
+template <typename T>
+__device__ __forceinline__ void load_row(Row& r, const T* x, int D, int lane) {
+#pragma unroll
+  for (int t = 0; t < MAXC; ++t) {
+    const int c = (lane + 64 * t) * 8;
+    if (c < D) {
+      load8<T>(x + c, r.v[t]);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) r.v[t][e] = 0.f;
+    }
+  }
+}
+
+// two-pass mean / rstd of the row held in r (biased variance, eps inside the sqrt)
+__device__ __forceinline__ void row_stats(const Row& r, int D, int lane, float eps, float& mean, float& rstd) {
+  float s = 0.f;
+#pragma unroll
+  for (int t = 0; t < MAXC; ++t)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s += r.v[t][e];
+  mean = wave_sum(s) / (float)D;
+  float q = 0.f;
+#pragma unroll
+  for (int t = 0; t < MAXC; ++t) {
+    if ((lane + 64 * t) * 8 < D) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float d = r.v[t][e] - mean;
+        q = fmaf(d, d, q);
+      }
+    }
+  }
+  const float var = wave_sum(q) / (float)D;
+  rstd = 1.0f / sqrtf(var + eps);
+}
+
+__device__ __forceinline__ void normalize_row(Row& r, int D, int lane, float mean, float rstd,
+                                              const float* w, const float* b) {
+#pragma unroll
+  for (int t = 0; t < MAXC; ++t) {
+    const int c = (lane + 64 * t) * 8;
+    if (c < D) {
+      float wv[8], bv[8];
+      load8<float>(w + c, wv);
+      load8<float>(b + c, bv);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) r.v[t][e] = fmaf((r.v[t][e] - mean) * rstd, wv[e], bv[e]);
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void ln_stats_kernel(const T* __restrict__ x, int64_t ldx, int M, int D,
+                                                       float eps, float* __restrict__ stats) {
+  const int lane = threadIdx.x & 63;
+  const int m = blockIdx.x * ROWS_PER_WG + (threadIdx.x >> 6);
+  if (m >= M) return;
+  Row r;
+  load_row<T>(r, x + (int64_t)m * ldx, D, lane);
+  float mean, rstd;
+  row_stats(r, D, lane, eps, mean, rstd);
+  if (lane == 0) *(float2*)(stats + 2 * (int64_t)m) = make_float2(mean, rstd);
+}
+
+template <typename TO>
+__global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict__ x, int64_t ldx,
+                                                        TO* __restrict__ out, int64_t ldo, int M, int D,
+                                                        const float* __restrict__ w,
+                                                        const float* __restrict__ b, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int m = blockIdx.x * ROWS_PER_WG + (threadIdx.x >> 6);
+  if (m >= M) return;
+  Row r;
+  load_row<bf16_t>(r, x + (int64_t)m * ldx, D, lane);
+  float mean, rstd;
+  row_stats(r, D, lane, eps, mean, rstd);
+  normalize_row(r, D, lane, mean, rstd, w, b);
+  TO* o = out + (int64_t)m * ldo;
+#pragma unroll
+  for (int t = 0; t < MAXC; ++t) {
+    const int c = (lane + 64 * t) * 8;
+    if (c < D) store8(o + c, r.v[t]);
+  }
+}
+
+__global__ __launch_bounds__(256) void embed_finalize_kernel(bf16_t* __restrict__ x, int64_t ldx, int rows,
+                                                             int ntok, int D, const float* __restrict__ cls,
+                                                             const float* __restrict__ pos,
+                                                             const float* __restrict__ en_w,
+                                                             const float* __restrict__ en_b, float en_eps,
+                                                             const float* __restrict__ np_w,
+                                                             const float* __restrict__ np_b, float np_eps) {
+  const int lane = threadIdx.x & 63;
+  const int m = blockIdx.x * ROWS_PER_WG + (threadIdx.x >> 6);
+  if (m >= rows) return;
+  const int n = m % ntok;
+  bf16_t* xr = x + (int64_t)m * ldx;
+  Row r;
+  float mean, rstd;
+  if (n == 0 && cls != nullptr) {
+    load_row<float>(r, cls, D, lane);
+  } else {
+    load_row<bf16_t>(r, xr, D, lane);
+    if (en_w != nullptr) {  // PatchEmbed.norm_layer acts on patch tokens only
+      row_stats(r, D, lane, en_eps, mean, rstd);
+      normalize_row(r, D, lane, mean, rstd, en_w, en_b);
+    }
+  }
+  if (np_w != nullptr) {
+    row_stats(r, D, lane, np_eps, mean, rstd);
+    normalize_row(r, D, lane, mean, rstd, np_w, np_b);
+  }
+#pragma unroll
+  for (int t = 0; t < MAXC; ++t) {
+    const int c = (lane + 64 * t) * 8;
+    if (c < D) {
+      if (pos != nullptr) {
+        float pv[8];
+        load8<float>(pos + (int64_t)n * D + c, pv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) r.v[t][e] += pv[e];
+      }
+      store8(xr + c, r.v[t]);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void scale_channels_kernel(const bf16_t* __restrict__ x, int64_t ldx,
+                                                             bf16_t* __restrict__ out, int64_t ldo, int M,
+                                                             int D, const float* __restrict__ gamma) {
+  const int cpr = D / 8;
+  const int64_t total = (int64_t)M * cpr;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t m = i / cpr;
+    const int c = (int)(i - m * cpr) * 8;
+    float v[8], g[8];
+    load8<bf16_t>(x + m * ldx + c, v);
+    load8<float>(gamma + c, g);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] *= g[e];
+    store8(out + m * ldo + c, v);
+  }
+}
+
+__device__ __forceinline__ float block_sum_256(float v, float* sh) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+// one workgroup per output row n
+template <typename TW>
+__global__ __launch_bounds__(256) void prepack_linear_kernel(const TW* __restrict__ w, const float* __restrict__ bias,
+                                                             const float* __restrict__ ln_g,
+                                                             const float* __restrict__ ln_b,
+                                                             const float* __restrict__ oscale, int K, int kpad,
+                                                             bf16_t* __restrict__ wp, float* __restrict__ s,
+                                                             float* __restrict__ c, float* __restrict__ g) {
+  __shared__ float sh[4];
+  const int n = blockIdx.x;
+  const TW* wr = w + (int64_t)n * K;
+  bf16_t* wo = wp + (int64_t)n * kpad;
+  float ssum = 0.f, csum = 0.f;
+  for (int k = threadIdx.x; k < kpad; k += 256) {
+    bf16_t o = 0;
+    if (k < K) {
+      float wv;
+      if (sizeof(TW) == 2) wv = bf2f(*(const bf16_t*)(wr + k)); else wv = *(const float*)(wr + k);
+      const float gk = ln_g ? ln_g[k] : 1.0f;
+      o = f2bf(wv * gk);
+      ssum += bf2f(o);
+      if (ln_b) csum = fmaf(ln_b[k], wv, csum);
+    }
+    wo[k] = o;
+  }
+  ssum = block_sum_256(ssum, sh);
+  csum = block_sum_256(csum, sh);
+  if (threadIdx.x == 0) {
+    const float os = oscale ? oscale[n] : 1.0f;
+    if (s) s[n] = ssum;
+    c[n] = (csum + (bias ? bias[n] : 0.f)) * os;
+    if (g) g[n] = os;
+  }
+}
+
+__global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int64_t n) {
+  const int64_t n8 = n / 8;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+    float v[8];
+    load8<float>(src + i * 8, v);
+    store8(dst + i * 8, v);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 7)) dst[n8 * 8 + threadIdx.x] = f2bf(src[n8 * 8 + threadIdx.x]);
+}
+__global__ __launch_bounds__(256) void cast_bf16_f32_kernel(const bf16_t* __restrict__ src, float* __restrict__ dst, int64_t n) {
+  const int64_t n8 = n / 8;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+    float v[8];
+    load8<bf16_t>(src + i * 8, v);
+    store8(dst + i * 8, v);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 7)) dst[n8 * 8 + threadIdx.x] = bf2f(src[n8 * 8 + threadIdx.x]);
+}
+
+inline bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+inline unsigned row_grid(int M) { return (unsigned)((M + ROWS_PER_WG - 1) / ROWS_PER_WG); }
+inline unsigned stream_grid(int64_t items) {
+  int64_t g = (items + 255) / 256;
+  return (unsigned)(g < 1 ? 1 : (g > 2048 ? 2048 : g));
+}
+
+}  // namespace
+
+extern "C" int vitm_ln_stats(const void* x, int x_dtype, int64_t ldx, int M, int D, float eps, float* stats,
+                             vitm_stream_t stream) {
+  VITM_REQUIRE(x && stats, "vitm_ln_stats: null pointer");
+  VITM_REQUIRE(M > 0 && D > 0 && D % 8 == 0 && D <= MAXD, "vitm_ln_stats: D=%d must be a multiple of 8 and <= %d", D, MAXD);
+  VITM_REQUIRE(ldx >= D && ldx % 8 == 0 && al16(x) && ((uintptr_t)stats & 7) == 0, "vitm_ln_stats: ldx/alignment");
+  hipStream_t st = (hipStream_t)stream;
+  if (x_dtype == VITM_BF16) {
+    hipLaunchKernelGGL(ln_stats_kernel<bf16_t>, dim3(row_grid(M)), dim3(256), 0, st, (const bf16_t*)x, ldx, M, D, eps, stats);
+  } else if (x_dtype == VITM_F32) {
+    hipLaunchKernelGGL(ln_stats_kernel<float>, dim3(row_grid(M)), dim3(256), 0, st, (const float*)x, ldx, M, D, eps, stats);
+  } else {
+    vitm_set_error("vitm_ln_stats: bad x_dtype %d", x_dtype);
+    return VITM_EINVAL;
+  }
+  VITM_CHECK_LAUNCH("vitm_ln_stats");
+  return VITM_OK;
+}
+
+extern "C" int vitm_layernorm(const void* x, int64_t ldx, void* out, int out_dtype, int64_t ldo, int M, int D,
+                              const float* w, const float* b, float eps, vitm_stream_t stream) {
+  VITM_REQUIRE(x && out && w && b, "vitm_layernorm: null pointer");
+  VITM_REQUIRE(M > 0 && D > 0 && D % 8 == 0 && D <= MAXD, "vitm_layernorm: D=%d must be a multiple of 8 and <= %d", D, MAXD);
+  VITM_REQUIRE(ldx >= D && ldo >= D && ldx % 8 == 0 && ldo % 8 == 0 && al16(x) && al16(out) && al16(w) && al16(b),
+               "vitm_layernorm: leading dimensions must be multiples of 8 and pointers 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  if (out_dtype == VITM_BF16) {
+    hipLaunchKernelGGL(layernorm_kernel<bf16_t>, dim3(row_grid(M)), dim3(256), 0, st, (const bf16_t*)x, ldx, (bf16_t*)out, ldo, M, D, w, b, eps);
+  } else if (out_dtype == VITM_F32) {
+    hipLaunchKernelGGL(layernorm_kernel<float>, dim3(row_grid(M)), dim3(256), 0, st, (const bf16_t*)x, ldx, (float*)out, ldo, M, D, w, b, eps);
+  } else {
+    vitm_set_error("vitm_layernorm: bad out_dtype %d", out_dtype);
+    return VITM_EINVAL;
+  }
+  VITM_CHECK_LAUNCH("vitm_layernorm");
+  return VITM_OK;
+}
+
+extern "C" int vitm_embed_finalize(void* x, int64_t ldx, int B, int ntok, int D, const float* cls,
+                                   const float* pos, const float* en_w, const float* en_b, float en_eps,
+                                   const float* np_w, const float* np_b, float np_eps, vitm_stream_t stream) {
+  VITM_REQUIRE(x, "vitm_embed_finalize: null x");
+  VITM_REQUIRE(B > 0 && ntok > 0 && D > 0 && D % 8 == 0 && D <= MAXD, "vitm_embed_finalize: D=%d must be a multiple of 8 and <= %d", D, MAXD);
+  VITM_REQUIRE(ldx >= D && ldx % 8 == 0 && al16(x), "vitm_embed_finalize: ldx/alignment");
+  VITM_REQUIRE((en_w == nullptr) == (en_b == nullptr) && (np_w == nullptr) == (np_b == nullptr),
+               "vitm_embed_finalize: LayerNorm weight and bias must be given together");
+  VITM_REQUIRE(al16(cls) && al16(pos) && al16(en_w) && al16(en_b) && al16(np_w) && al16(np_b), "vitm_embed_finalize: vectors must be 16-byte aligned");
+  const int rows = B * ntok;
+  hipLaunchKernelGGL(embed_finalize_kernel, dim3(row_grid(rows)), dim3(256), 0, (hipStream_t)stream, (bf16_t*)x, ldx, rows,
+                     ntok, D, cls, pos, en_w, en_b, en_eps, np_w, np_b, np_eps);
+  VITM_CHECK_LAUNCH("vitm_embed_finalize");
+  return VITM_OK;
+}
+
+extern "C" int vitm_scale_channels(const void* x, int64_t ldx, void* out, int64_t ldo, int M, int D,
+                                   const float* gamma, vitm_stream_t stream) {
+  VITM_REQUIRE(x && out && gamma, "vitm_scale_channels: null pointer");
+  VITM_REQUIRE(M > 0 && D > 0 && D % 8 == 0 && ldx >= D && ldo >= D && ldx % 8 == 0 && ldo % 8 == 0, "vitm_scale_channels: D/ld must be multiples of 8");
+  VITM_REQUIRE(al16(x) && al16(out) && al16(gamma), "vitm_scale_channels: pointers must be 16-byte aligned");
+  hipLaunchKernelGGL(scale_channels_kernel, dim3(stream_grid((int64_t)M * (D / 8))), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)x, ldx, (bf16_t*)out, ldo, M, D, gamma);
+  VITM_CHECK_LAUNCH("vitm_scale_channels");
+  return VITM_OK;
+}
+
+extern "C" int vitm_prepack_linear(const void* w, int w_dtype, const float* bias, const float* ln_gamma,
+                                   const float* ln_beta, const float* out_scale, int N, int K, int kpad,
+                                   void* wp, float* s, float* c, float* g, vitm_stream_t stream) {
+  VITM_REQUIRE(w && wp && c, "vitm_prepack_linear: null w/wp/c");
+  VITM_REQUIRE(N > 0 && K > 0 && kpad >= K, "vitm_prepack_linear: bad N/K/kpad");
+  hipStream_t st = (hipStream_t)stream;
+  if (w_dtype == VITM_F32) {
+    hipLaunchKernelGGL(prepack_linear_kernel<float>, dim3((unsigned)N), dim3(256), 0, st, (const float*)w, bias, ln_gamma, ln_beta,
+                       out_scale, K, kpad, (bf16_t*)wp, s, c, g);
+  } else if (w_dtype == VITM_BF16) {
+    hipLaunchKernelGGL(prepack_linear_kernel<bf16_t>, dim3((unsigned)N), dim3(256), 0, st, (const bf16_t*)w, bias, ln_gamma, ln_beta,
+                       out_scale, K, kpad, (bf16_t*)wp, s, c, g);
+  } else {
+    vitm_set_error("vitm_prepack_linear: bad w_dtype %d", w_dtype);
+    return VITM_EINVAL;
+  }
+  VITM_CHECK_LAUNCH("vitm_prepack_linear");
+  return VITM_OK;
+}
+
+extern "C" int vitm_cast_f32_to_bf16(const float* src, void* dst, int64_t n, vitm_stream_t stream) {
+  VITM_REQUIRE(src && dst && n > 0, "vitm_cast_f32_to_bf16: bad arguments");
+  VITM_REQUIRE(al16(src) && al16(dst), "vitm_cast_f32_to_bf16: pointers must be 16-byte aligned");
+  hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(stream_grid(n / 8)), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, n);
+  VITM_CHECK_LAUNCH("vitm_cast_f32_to_bf16");
+  return VITM_OK;
+}
+
+extern "C" int vitm_cast_bf16_to_f32(const void* src, float* dst, int64_t n, vitm_stream_t stream) {
+  VITM_REQUIRE(src && dst && n > 0, "vitm_cast_bf16_to_f32: bad arguments");
+  VITM_REQUIRE(al16(src) && al16(dst), "vitm_cast_bf16_to_f32: pointers must be 16-byte aligned");
+  hipLaunchKernelGGL(cast_bf16_f32_kernel, dim3(stream_grid(n / 8)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, dst, n);
+  VITM_CHECK_LAUNCH("vitm_cast_bf16_to_f32");
+  return VITM_OK;
+}

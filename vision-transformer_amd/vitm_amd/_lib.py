@@ -1,0 +1,89 @@
+"""ctypes binding of libvitm_gfx950.so (the C ABI declared in include/vitm_gfx950.h).
+
+The library is the product's only compute path.  It is loaded lazily and loading failures are
+fatal (``VitmLibraryError``): there is no PyTorch or CPU fallback behind it.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import threading
+from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.environ.get(
+    "VITM_GFX950_LIB", os.path.join(os.path.dirname(_HERE), "lib", "libvitm_gfx950.so"))
+
+BF16, F32 = 0, 1
+EPI_BIAS, EPI_BIAS_GELU, EPI_LN, EPI_LN_GELU, EPI_RESIDUAL = 0, 1, 2, 3, 4
+
+
+class VitmLibraryError(RuntimeError):
+    pass
+
+
+class VitmError(RuntimeError):
+    pass
+
+
+# name -> (restype, argtypes); must list every function include/vitm_gfx950.h declares
+SIGNATURES = {
+    "vitm_version": (c_char_p, []),
+    "vitm_last_error": (c_char_p, []),
+    "vitm_gemm_k_multiple": (c_int, []),
+    "vitm_prepack_linear": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "vitm_ln_stats": (c_int, [c_void_p, c_int, c_int64, c_int, c_int, c_float, c_void_p, c_void_p]),
+    "vitm_gemm": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int,
+                          c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+    "vitm_patch_embed": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int64, c_int,
+                                 c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
+    "vitm_embed_finalize": (c_int, [c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                    c_float, c_void_p, c_void_p, c_float, c_void_p]),
+    "vitm_attention": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_float, c_void_p]),
+    "vitm_layernorm": (c_int, [c_void_p, c_int64, c_void_p, c_int, c_int64, c_int, c_int, c_void_p, c_void_p,
+                               c_float, c_void_p]),
+    "vitm_scale_channels": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p]),
+    "vitm_cast_f32_to_bf16": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
+    "vitm_cast_bf16_to_f32": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
+}
+
+_lib = None
+_lock = threading.Lock()
+
+
+def load() -> ctypes.CDLL:
+    """Load the shared library once; raise VitmLibraryError when it is absent or incomplete."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise VitmLibraryError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                f"or `make -C vision-transformer_amd/csrc` (there is no fallback path)")
+        try:
+            lib = ctypes.CDLL(LIB_PATH)
+        except OSError as e:  # pragma: no cover - depends on the host
+            raise VitmLibraryError(f"cannot load {LIB_PATH}: {e}") from e
+        for name, (res, args) in SIGNATURES.items():
+            try:
+                fn = getattr(lib, name)
+            except AttributeError as e:
+                raise VitmLibraryError(f"{LIB_PATH} does not export {name}") from e
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def check(status: int, what: str) -> None:
+    if status != 0:
+        msg = load().vitm_last_error().decode("utf-8", "replace")
+        raise VitmError(f"{what} failed ({status}): {msg}")
+
+
+def version() -> str:
+    return load().vitm_version().decode()

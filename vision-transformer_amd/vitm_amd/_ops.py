@@ -1,0 +1,175 @@
+"""Torch-tensor front end of the C ABI: argument checking, packing caches and launch helpers.
+
+PyTorch supplies device memory and the current stream; every computation below is a call into
+libvitm_gfx950.so.  Nothing here computes with torch ops on the data path.
+"""
+from __future__ import annotations
+
+from ctypes import c_void_p
+from typing import Optional, Sequence
+
+import torch
+
+from . import _lib
+from ._lib import BF16, F32, EPI_BIAS, EPI_BIAS_GELU, EPI_LN, EPI_LN_GELU, EPI_RESIDUAL  # noqa: F401
+
+
+def round_up(a: int, b: int) -> int:
+    return (a + b - 1) // b * b
+
+
+def k_multiple() -> int:
+    return _lib.load().vitm_gemm_k_multiple()
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else c_void_p(t.data_ptr())
+
+
+def _stream():
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_cuda(x: torch.Tensor, what: str) -> None:
+    if not x.is_cuda:
+        raise RuntimeError(
+            f"{what}: vitm_amd computes only on an MI355X through libvitm_gfx950 -- move the module and its "
+            f"input to a 'cuda' device (got a {x.device} tensor; there is no CPU path)")
+
+
+def _dt(t: torch.Tensor) -> int:
+    if t.dtype == torch.bfloat16:
+        return BF16
+    if t.dtype == torch.float32:
+        return F32
+    raise TypeError(f"unsupported dtype {t.dtype} (bf16 or fp32)")
+
+
+def f32vec(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+    """A parameter vector as a contiguous fp32 tensor (no copy when it already is one)."""
+    if t is None:
+        return None
+    return t.detach().to(torch.float32).contiguous()
+
+
+class PackedLinear:
+    """bf16 weight [npad, kpad] (+ folded LayerNorm / LayerScale vectors) ready for vitm_gemm."""
+    __slots__ = ("wp", "s", "c", "g", "N", "K", "npad", "kpad")
+
+    def __init__(self, wp, s, c, g, N, K, npad, kpad):
+        self.wp, self.s, self.c, self.g = wp, s, c, g
+        self.N, self.K, self.npad, self.kpad = N, K, npad, kpad
+
+
+def pack_linear(weight: torch.Tensor, bias: Optional[torch.Tensor] = None,
+                ln_weight: Optional[torch.Tensor] = None, ln_bias: Optional[torch.Tensor] = None,
+                out_scale: Optional[torch.Tensor] = None) -> PackedLinear:
+    """Run vitm_prepack_linear on an (N, K...) weight; N is padded to 8 and K to the GEMM's K multiple."""
+    lib = _lib.load()
+    w = weight.detach()
+    if w.dtype not in (torch.bfloat16, torch.float32):
+        w = w.float()
+    w = w.reshape(w.shape[0], -1).contiguous()
+    N, K = w.shape
+    npad, kpad = round_up(N, 8), round_up(K, k_multiple())
+    dev = w.device
+    wp = torch.zeros((npad, kpad), dtype=torch.bfloat16, device=dev)
+    fold_ln = ln_weight is not None
+    s = torch.zeros(npad, dtype=torch.float32, device=dev) if fold_ln else None
+    c = torch.zeros(npad, dtype=torch.float32, device=dev)
+    g = torch.zeros(npad, dtype=torch.float32, device=dev) if out_scale is not None else None
+    b32, lw32, lb32, os32 = f32vec(bias), f32vec(ln_weight), f32vec(ln_bias), f32vec(out_scale)
+    if fold_ln and lb32 is None:
+        lb32 = torch.zeros_like(lw32)
+    _lib.check(lib.vitm_prepack_linear(_p(w), _dt(w), _p(b32), _p(lw32), _p(lb32), _p(os32), N, K, kpad,
+                                       _p(wp), _p(s), _p(c), _p(g), _stream()), "vitm_prepack_linear")
+    return PackedLinear(wp, s, c, g, N, K, npad, kpad)
+
+
+def cached_pack(owner, slot: str, tensors: Sequence[Optional[torch.Tensor]], build):
+    """Memoise a packed weight on ``owner`` until one of the source tensors changes."""
+    key = tuple((t.data_ptr(), t._version, t.dtype, t.device) if t is not None else None for t in tensors)
+    cache = owner.__dict__.setdefault("_vitm_packs", {})
+    hit = cache.get(slot)
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    val = build()
+    cache[slot] = (key, val)
+    return val
+
+
+def ln_stats(x: torch.Tensor, M: int, D: int, eps: float, stats: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x is a 2-D (rows, ld) view; returns [M, 2] fp32 (mean, rstd)."""
+    if stats is None:
+        stats = torch.empty((M, 2), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().vitm_ln_stats(_p(x), _dt(x), x.stride(0), M, D, float(eps), _p(stats), _stream()),
+               "vitm_ln_stats")
+    return stats
+
+
+def gemm(A: torch.Tensor, pk: PackedLinear, out: torch.Tensor, epilogue: int, M: int,
+         stats: Optional[torch.Tensor] = None, resid: Optional[torch.Tensor] = None, row_group: int = 0) -> torch.Tensor:
+    """out[:, :npad] = epilogue(A[:, :kpad] . wp^T); A, out (and resid) are 2-D row-major views."""
+    assert A.dtype == torch.bfloat16 and A.stride(1) == 1 and out.stride(1) == 1
+    assert A.shape[1] >= pk.kpad, "A operand narrower than the packed K"
+    _lib.check(_lib.load().vitm_gemm(
+        _p(A), A.stride(0), _p(pk.wp), pk.kpad, _p(out), out.stride(0), _dt(out), M, pk.npad, pk.kpad, epilogue,
+        _p(stats), _p(pk.s), _p(pk.c), _p(pk.g), _p(resid), 0 if resid is None else resid.stride(0), row_group,
+        _stream()), "vitm_gemm")
+    return out
+
+
+def patch_embed(img: torch.Tensor, pk: PackedLinear, tokens: torch.Tensor, patch, D: int, cls_slot: bool) -> None:
+    B, C, H, W = img.shape
+    _lib.check(_lib.load().vitm_patch_embed(
+        _p(img), _dt(img), B, C, H, W, patch[0], patch[1], _p(pk.wp), pk.kpad, pk.kpad, _p(pk.c), _p(tokens),
+        tokens.stride(0), D, 1 if cls_slot else 0, _stream()), "vitm_patch_embed")
+
+
+def embed_finalize(x: torch.Tensor, B: int, ntok: int, D: int, cls, pos, en_w, en_b, en_eps, np_w, np_b, np_eps) -> None:
+    _lib.check(_lib.load().vitm_embed_finalize(
+        _p(x), x.stride(0), B, ntok, D, _p(cls), _p(pos), _p(en_w), _p(en_b), float(en_eps), _p(np_w), _p(np_b),
+        float(np_eps), _stream()), "vitm_embed_finalize")
+
+
+def attention(qkv: torch.Tensor, out: torch.Tensor, B: int, N: int, H: int, hd: int, scale: float) -> None:
+    _lib.check(_lib.load().vitm_attention(_p(qkv), qkv.stride(0), _p(out), out.stride(0), B, N, H, hd, float(scale),
+                                          _stream()), "vitm_attention")
+
+
+def layernorm(x: torch.Tensor, out: torch.Tensor, M: int, D: int, w: torch.Tensor, b: torch.Tensor, eps: float) -> None:
+    _lib.check(_lib.load().vitm_layernorm(_p(x), x.stride(0), _p(out), _dt(out), out.stride(0), M, D, _p(w), _p(b),
+                                          float(eps), _stream()), "vitm_layernorm")
+
+
+def scale_channels(x: torch.Tensor, out: torch.Tensor, M: int, D: int, gamma: torch.Tensor) -> None:
+    _lib.check(_lib.load().vitm_scale_channels(_p(x), x.stride(0), _p(out), out.stride(0), M, D, _p(gamma), _stream()),
+               "vitm_scale_channels")
+
+
+def to_bf16(x: torch.Tensor) -> torch.Tensor:
+    """A contiguous bf16 copy of a contiguous fp32/bf16 CUDA tensor (cast kernel, not torch)."""
+    x = x.contiguous()
+    if x.dtype == torch.bfloat16:
+        return x
+    if x.dtype != torch.float32:
+        raise TypeError(f"unsupported activation dtype {x.dtype} (bf16 or fp32)")
+    out = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    if x.numel():
+        _lib.check(_lib.load().vitm_cast_f32_to_bf16(_p(x), _p(out), x.numel(), _stream()), "vitm_cast_f32_to_bf16")
+    return out
+
+
+def to_f32(x: torch.Tensor) -> torch.Tensor:
+    x = x.contiguous()
+    if x.dtype == torch.float32:
+        return x
+    out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    if x.numel():
+        _lib.check(_lib.load().vitm_cast_bf16_to_f32(_p(x), _p(out), x.numel(), _stream()), "vitm_cast_bf16_to_f32")
+    return out
+
+
+def like_input(y_bf16: torch.Tensor, ref: torch.Tensor) -> torch.Tensor:
+    """Return the bf16 result in the caller's dtype (fp32 callers get an fp32 tensor back)."""
+    return to_f32(y_bf16) if ref.dtype == torch.float32 else y_bf16

@@ -1,0 +1,7 @@
+"""Public model API; the four names the reference exports (vitm/models/__init__.py:1-12) plus the
+block-level classes it keeps in ``vitm.models.models``."""
+from .patch_embeddings import PatchEmbed
+from .models import VisionTransformer, Attention, MLP, Mlp, LayerScale, Block
+from .classifier import VITC
+
+__all__ = ["VisionTransformer", "VITC", "Attention", "PatchEmbed", "MLP", "Mlp", "LayerScale", "Block"]

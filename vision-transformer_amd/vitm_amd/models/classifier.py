@@ -1,0 +1,56 @@
+"""Classification wrapper: backbone -> class-token row -> linear head.
+
+API mirror of the reference's ``VITC`` (vitm/models/classifier.py:6-39): ``VITC(vit_model)`` with
+attributes ``vit_model`` and ``head = nn.Linear(embed_dim, num_classes)`` and state_dict keys
+``vit_model.*``, ``head.{weight,bias}``.  When the backbone is this package's ``VisionTransformer`` the final
+LayerNorm is applied to the class-token rows only and folded into the head GEMM.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from .. import _ops
+from .models import VisionTransformer
+from .patch_embeddings import layernorm_params
+
+
+class VITC(nn.Module):
+    def __init__(self, vit_model: VisionTransformer):
+        super().__init__()
+        self.vit_model = vit_model
+        self.head = nn.Linear(self.vit_model.embed_dim, self.vit_model.num_classes)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        """(B, C, H, W) images -> (B, num_classes) logits, in the dtype of ``x``."""
+        _ops.require_cuda(x, "VITC.forward")
+        vt = self.vit_model
+        C = self.head.out_features
+        with torch.cuda.device(x.device):
+            if isinstance(vt, VisionTransformer):
+                x2d, B, N, D = vt._run_blocks(x)              # pre-final-norm tokens, rows (b, n), bf16
+                cls_rows = x2d.view(B, N, x2d.shape[1])[:, 0]  # (B, ld) view with row stride N*ld
+                ln = layernorm_params(vt.norm_final, "VisionTransformer.norm_final")
+            else:                                             # foreign backbone: take its output as is
+                emb = vt(x)
+                B, N, D = emb.shape
+                cls_rows = _ops.to_bf16(emb[:, 0].contiguous())
+                kp = _ops.round_up(D, _ops.k_multiple())
+                if kp != D:
+                    pad = torch.zeros((B, kp), dtype=torch.bfloat16, device=x.device)
+                    pad[:, :D] = cls_rows
+                    cls_rows = pad
+                ln = None
+            w, b = self.head.weight, self.head.bias
+            out_dtype = torch.float32 if x.dtype == torch.float32 else torch.bfloat16
+            if ln is not None:
+                pk = _ops.cached_pack(self, "head_ln", (w, b, ln[0], ln[1]),
+                                      lambda: _ops.pack_linear(w, b, ln[0], ln[1]))
+                stats = _ops.ln_stats(cls_rows, B, D, ln[2])
+                logits = torch.empty((B, pk.npad), dtype=out_dtype, device=x.device)
+                _ops.gemm(cls_rows, pk, logits, _ops.EPI_LN, B, stats=stats)
+            else:
+                pk = _ops.cached_pack(self, "head", (w, b), lambda: _ops.pack_linear(w, b))
+                logits = torch.empty((B, pk.npad), dtype=out_dtype, device=x.device)
+                _ops.gemm(cls_rows, pk, logits, _ops.EPI_BIAS, B)
+            return logits[:, :C]

@@ -1,0 +1,429 @@
+"""Transformer encoder modules of the ViT, computing on MI355X.
+
+API mirror of the reference's vitm/models/models.py -- ``Attention`` (:27-95), ``MLP`` (:98-130),
+``LayerScale`` (:132-139), ``Block`` (:142-211), ``VisionTransformer`` (:215-416) -- with the same
+constructor arguments, attribute names and state_dict keys, so reference checkpoints load with
+``load_state_dict(strict=True)``.  Every ``forward`` is a short sequence of C-ABI calls
+(include/vitm_gfx950.h); activations travel as bf16 with fp32 accumulation and come back in the dtype of
+the input.  The path is forward-only (no autograd graph is recorded).
+
+Deliberate differences from the reference's HEAD, all supersets of what can run there:
+  * ``forward_heads`` iterates ``self.blocks`` (the reference calls the ModuleList, models.py:409, which raises);
+  * ``embed_dim`` is forwarded to ``embed_layer`` (models.py:291-295 drops it, so only 768 works there);
+  * ``norm_layer=None`` leaves ``norm_pre`` an Identity and lets the blocks use their LayerNorm default
+    (the reference passes None into Block, models.py:317, and fails);
+  * ``fused_attention=True`` runs the same fused kernel (the reference branch is a stub, models.py:84-85).
+"""
+from __future__ import annotations
+
+from functools import partial
+from typing import Optional, Tuple, Type, Union
+
+import torch
+import torch.nn as nn
+
+from .. import _ops
+from ..utils.helper import to_2tuple
+from .patch_embeddings import PatchEmbed, layernorm_params
+
+_SUPPORTED_HEAD_DIMS = (32, 64, 96, 128)
+
+
+def _check_gelu(act: nn.Module, what: str) -> None:
+    if not (isinstance(act, nn.GELU) and getattr(act, "approximate", "none") == "none"):
+        raise NotImplementedError(f"{what}: only nn.GELU() (exact erf form) is fused on the HIP path, got {act!r}")
+
+
+def _as_rows(x: torch.Tensor, D: int) -> Tuple[torch.Tensor, int]:
+    """(..., D) CUDA activation -> contiguous bf16 [M, kpad(D)] (pad columns zero) and M."""
+    M = x.numel() // D
+    xb = _ops.to_bf16(x.reshape(M, D))
+    kp = _ops.round_up(D, _ops.k_multiple())
+    if kp != D:
+        padded = torch.zeros((M, kp), dtype=torch.bfloat16, device=x.device)
+        padded[:, :D] = xb
+        xb = padded
+    return xb, M
+
+
+def _act_buffer(M: int, width: int, device, zero_pad_from: Optional[int] = None) -> torch.Tensor:
+    """bf16 [M, kpad(width)] activation buffer; zero-filled when it has pad columns a later GEMM reads."""
+    kp = _ops.round_up(width, _ops.k_multiple())
+    if kp != (zero_pad_from if zero_pad_from is not None else width):
+        return torch.zeros((M, kp), dtype=torch.bfloat16, device=device)
+    return torch.empty((M, kp), dtype=torch.bfloat16, device=device)
+
+
+class Attention(nn.Module):
+    """Multi-head self-attention: qkv projection, softmax(q k^T / sqrt(hd)) v, output projection."""
+
+    def __init__(self, dim: int, num_heads: int = 8, qkv_bias: bool = False, fused_attention: bool = False,
+                 qk_norm: bool = False, proj_bias=True, norm_layer=nn.LayerNorm):
+        super().__init__()
+        self.dim = dim
+        self.num_heads = num_heads
+        self.head_dim = self.dim // self.num_heads
+        self.qkv_bias = qkv_bias
+        self.fused_attention = fused_attention
+        self.qk_norm = qk_norm
+        self.scale = self.head_dim ** -0.5
+        self.qkv = nn.Linear(dim, dim * 3, bias=self.qkv_bias)
+        self.q_norm = norm_layer(self.head_dim) if qk_norm else nn.Identity()
+        self.k_norm = norm_layer(self.head_dim) if qk_norm else nn.Identity()
+        self.proj = nn.Linear(dim, dim, bias=proj_bias)
+        self._init_weights()
+
+    def _init_weights(self):
+        for lin in (self.qkv, self.proj):   # models.py:61-70
+            nn.init.trunc_normal_(lin.weight, std=0.02)
+            if lin.bias is not None:
+                nn.init.zeros_(lin.bias)
+
+    # ---- HIP path --------------------------------------------------------------------------------
+    def _check(self):
+        if self.qk_norm:
+            raise NotImplementedError("Attention(qk_norm=True) is not on the HIP path yet")
+        if self.head_dim * self.num_heads != self.dim or self.head_dim not in _SUPPORTED_HEAD_DIMS:
+            raise NotImplementedError(f"head_dim {self.dim}/{self.num_heads} unsupported; the fused attention kernel "
+                                      f"handles head_dim in {_SUPPORTED_HEAD_DIMS}")
+
+    def _qkv_pack(self, ln=None) -> _ops.PackedLinear:
+        w, b = self.qkv.weight, self.qkv.bias
+        if ln is None:
+            return _ops.cached_pack(self, "qkv", (w, b), lambda: _ops.pack_linear(w, b))
+        return _ops.cached_pack(self, "qkv_ln", (w, b, ln[0], ln[1]), lambda: _ops.pack_linear(w, b, ln[0], ln[1]))
+
+    def _proj_pack(self, gamma=None) -> _ops.PackedLinear:
+        w, b = self.proj.weight, self.proj.bias
+        if gamma is None:
+            return _ops.cached_pack(self, "proj", (w, b), lambda: _ops.pack_linear(w, b))
+        return _ops.cached_pack(self, "proj_ls", (w, b, gamma), lambda: _ops.pack_linear(w, b, out_scale=gamma))
+
+    def _core(self, qkv2d: torch.Tensor, o2d: torch.Tensor, B: int, N: int) -> None:
+        _ops.attention(qkv2d, o2d, B, N, self.num_heads, self.head_dim, self.scale)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        """(B, N, C) -> (B, N, C)."""
+        _ops.require_cuda(x, "Attention.forward")
+        self._check()
+        B, N, C = x.shape
+        with torch.cuda.device(x.device):
+            xb, M = _as_rows(x, C)
+            qkv = torch.empty((M, 3 * C), dtype=torch.bfloat16, device=x.device)
+            _ops.gemm(xb, self._qkv_pack(), qkv, _ops.EPI_BIAS, M)
+            o = _act_buffer(M, C, x.device)
+            self._core(qkv, o, B, N)
+            y = torch.empty((M, _ops.round_up(C, 8)), dtype=torch.bfloat16, device=x.device)
+            _ops.gemm(o, self._proj_pack(), y, _ops.EPI_BIAS, M)
+            return _ops.like_input(y[:, :C].reshape(B, N, C), x)
+
+
+class MLP(nn.Module):
+    """Two-layer feed-forward: linear -> GELU -> linear (models.py:98-130).
+
+    As in the reference, ``out_features`` is ignored (the output width is ``in_features``), ``bias`` may be a
+    bool or a pair, and ``norm_layer`` / ``vit`` are accepted and unused.  ``use_conv=True`` builds the 1x1
+    Conv2d layers (same parameter shapes) but that variant has no HIP forward.
+    """
+
+    def __init__(self, in_features, hidden_features: int = None, out_features: int = None, use_conv: bool = False,
+                 bias: bool = False, act_layer: Type[nn.Module] = nn.GELU, norm_layer=None, vit: bool = False):
+        super().__init__()
+        self.vit = vit
+        self.in_features = in_features
+        self.hidden_features = hidden_features if hidden_features is not None else self.in_features * 4
+        self.out_features = self.in_features or out_features
+        self.bias = to_2tuple(bias)
+        self.use_conv = use_conv
+        self.linear_layer = partial(nn.Conv2d, kernel_size=1) if use_conv else nn.Linear
+        self.linear_layer1 = self.linear_layer(self.in_features, self.hidden_features, bias=self.bias[0])
+        self.ac1 = act_layer()
+        self.linear_layer2 = self.linear_layer(self.hidden_features, self.out_features, bias=self.bias[1])
+
+    # ---- HIP path --------------------------------------------------------------------------------
+    def _fc1_pack(self, ln=None) -> _ops.PackedLinear:
+        w, b = self.linear_layer1.weight, self.linear_layer1.bias
+        if ln is None:
+            return _ops.cached_pack(self, "fc1", (w, b), lambda: _ops.pack_linear(w, b))
+        return _ops.cached_pack(self, "fc1_ln", (w, b, ln[0], ln[1]), lambda: _ops.pack_linear(w, b, ln[0], ln[1]))
+
+    def _fc2_pack(self, gamma=None) -> _ops.PackedLinear:
+        w, b = self.linear_layer2.weight, self.linear_layer2.bias
+        if gamma is None:
+            return _ops.cached_pack(self, "fc2", (w, b), lambda: _ops.pack_linear(w, b))
+        return _ops.cached_pack(self, "fc2_ls", (w, b, gamma), lambda: _ops.pack_linear(w, b, out_scale=gamma))
+
+    def _check(self):
+        if self.use_conv:
+            raise NotImplementedError("MLP(use_conv=True) has no HIP forward")
+        _check_gelu(self.ac1, "MLP")
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        """(..., in_features) -> (..., in_features)."""
+        _ops.require_cuda(x, "MLP.forward")
+        self._check()
+        C = self.in_features
+        with torch.cuda.device(x.device):
+            xb, M = _as_rows(x, C)
+            p1, p2 = self._fc1_pack(), self._fc2_pack()
+            h = _act_buffer(M, self.hidden_features, x.device, zero_pad_from=p1.npad)
+            _ops.gemm(xb, p1, h, _ops.EPI_BIAS_GELU, M)
+            y = torch.empty((M, p2.npad), dtype=torch.bfloat16, device=x.device)
+            _ops.gemm(h, p2, y, _ops.EPI_BIAS, M)
+            return _ops.like_input(y[:, :self.out_features].reshape(*x.shape[:-1], self.out_features), x)
+
+
+Mlp = MLP  # timm spelling
+
+
+class LayerScale(nn.Module):
+    """Per-channel learnable scale ``x * gamma`` (models.py:132-139)."""
+
+    def __init__(self, dim: int, init_values: float = 1e-5, inplace=False):
+        super().__init__()
+        self.gamma = nn.Parameter(torch.ones(dim) * init_values)
+        self.inplace = inplace
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        _ops.require_cuda(x, "LayerScale.forward")
+        D = self.gamma.numel()
+        if D % 8 != 0:
+            raise NotImplementedError("LayerScale on the HIP path needs dim % 8 == 0")
+        with torch.cuda.device(x.device):
+            M = x.numel() // D
+            g = _ops.f32vec(self.gamma)
+            if self.inplace and x.dtype == torch.bfloat16 and x.is_contiguous():
+                x2 = x.view(M, D)
+                _ops.scale_channels(x2, x2, M, D, g)
+                return x
+            xb = _ops.to_bf16(x.reshape(M, D))
+            out = torch.empty_like(xb)
+            _ops.scale_channels(xb, out, M, D, g)
+            y = _ops.like_input(out.reshape(x.shape), x)
+            if self.inplace:
+                x.copy_(y)
+                return x
+            return y
+
+
+class Block(nn.Module):
+    """Pre-norm transformer block: ``x += ls1(attn(norm1(x)))``; ``x += ls2(mlp(norm2(x)))`` (models.py:208-211).
+
+    Attention is built with the reference's defaults (no qkv bias, proj bias, no qk-norm, models.py:190-194) and
+    the MLP with biases on both layers and ``hidden = int(dim * mlp_ratio)`` (models.py:198-205).
+    On the HIP path a block is seven launches: LN statistics, LN-folded qkv GEMM, fused attention, proj GEMM with
+    bias + LayerScale + residual, LN statistics, LN-folded fc1 GEMM with GELU, fc2 GEMM with bias + LayerScale +
+    residual.
+    """
+
+    def __init__(self, dim: int, num_heads: int, mlp_ratio: float, norm_layer: Type[nn.Module] = nn.LayerNorm,
+                 act_layer: Type[nn.Module] = nn.GELU, mlp_layer=MLP, vit: bool = False):
+        super().__init__()
+        self.dim = dim
+        self.norm1 = norm_layer(dim)
+        self.attn = Attention(dim=dim, num_heads=num_heads, norm_layer=norm_layer)
+        self.ls1 = LayerScale(dim=dim)
+        self.norm2 = norm_layer(dim)
+        self.mlp = MLP(in_features=dim, hidden_features=int(dim * mlp_ratio), bias=True, norm_layer=norm_layer,
+                       act_layer=act_layer, vit=vit)
+        self.ls2 = LayerScale(dim=dim)
+
+    # ---- HIP path --------------------------------------------------------------------------------
+    def _run(self, x2d: torch.Tensor, B: int, N: int, ws: dict) -> None:
+        """In place on the residual stream x2d ([B*N, ld] bf16); ``ws`` holds the reusable work buffers."""
+        attn, mlp = self.attn, self.mlp
+        attn._check()
+        mlp._check()
+        D, M = self.dim, B * N
+        ln1 = layernorm_params(self.norm1, "Block.norm1")
+        ln2 = layernorm_params(self.norm2, "Block.norm2")
+        # attention branch
+        pk = attn._qkv_pack(ln1)
+        if ln1 is not None:
+            _ops.ln_stats(x2d, M, D, ln1[2], ws["stats"])
+            _ops.gemm(x2d, pk, ws["qkv"], _ops.EPI_LN, M, stats=ws["stats"])
+        else:
+            _ops.gemm(x2d, pk, ws["qkv"], _ops.EPI_BIAS, M)
+        attn._core(ws["qkv"], ws["o"], B, N)
+        _ops.gemm(ws["o"], attn._proj_pack(self.ls1.gamma), x2d, _ops.EPI_RESIDUAL, M, resid=x2d)
+        # MLP branch
+        pk = mlp._fc1_pack(ln2)
+        if ln2 is not None:
+            _ops.ln_stats(x2d, M, D, ln2[2], ws["stats"])
+            _ops.gemm(x2d, pk, ws["h"], _ops.EPI_LN_GELU, M, stats=ws["stats"])
+        else:
+            _ops.gemm(x2d, pk, ws["h"], _ops.EPI_BIAS_GELU, M)
+        _ops.gemm(ws["h"], mlp._fc2_pack(self.ls2.gamma), x2d, _ops.EPI_RESIDUAL, M, resid=x2d)
+
+    def _workspace(self, M: int, device) -> dict:
+        D = self.dim
+        hid_npad = _ops.round_up(self.mlp.hidden_features, 8)
+        return dict(stats=torch.empty((M, 2), dtype=torch.float32, device=device),
+                    qkv=torch.empty((M, 3 * D), dtype=torch.bfloat16, device=device),
+                    o=_act_buffer(M, D, device),
+                    h=_act_buffer(M, self.mlp.hidden_features, device, zero_pad_from=hid_npad))
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        """(B, N, D) -> (B, N, D)."""
+        _ops.require_cuda(x, "Block.forward")
+        B, N, D = x.shape
+        if D != self.dim:
+            raise RuntimeError(f"Block(dim={self.dim}) got an input with last dim {D}")
+        with torch.cuda.device(x.device):
+            xb, M = _as_rows(x, D)
+            if xb.data_ptr() == x.data_ptr():
+                xb = xb.clone()  # the block updates its residual stream in place; never the caller's tensor
+            self._run(xb, B, N, self._workspace(M, x.device))
+            return _ops.like_input(xb[:, :D].reshape(B, N, D), x)
+
+
+class VisionTransformer(nn.Module):
+    """timm-style ViT encoder: patch embedding, class token, ``norm_pre`` (applied BEFORE the positional
+    embedding is added, models.py:359-360), ``depth`` blocks, ``norm_final``; returns all tokens (B, N, D).
+
+    Constructor arguments are those of models.py:261-281.  ``parallel_block=True`` (the ViT-22B block) and
+    the DTensor helpers ``parallelize_blocks`` / ``spawn_parallel`` are outside this forward path.
+    """
+
+    def __init__(self, image_size: Union[int, Tuple[int, int]], patch_size: int, num_classes: int, num_heads: int,
+                 mlp_ratio: float, depth: int = 12, embed_dim: int = 768, block_fn=Block,
+                 norm_layer: Optional[nn.Module] = None, mlp_layer=MLP, pos_embed: str = "learn",
+                 embed_norm_layer: Optional[nn.Module] = None, embed_layer: Optional[nn.Module] = PatchEmbed,
+                 class_token: bool = True, final_norm_layer: Optional[nn.Module] = None,
+                 act_layer: Optional[nn.Module] = nn.GELU, parallel_block: bool = False,
+                 shard_along_dims: tuple = None):
+        super().__init__()
+        if parallel_block:
+            raise NotImplementedError("parallel_block=True (ViT-22B ParallelBlock) is outside the MI355X forward path")
+        self.embed_dim = embed_dim
+        self.num_classes = num_classes
+        self.image_size = image_size
+        self.patch_size = patch_size
+        embed_args = {}
+        if embed_norm_layer is not None:
+            embed_args["norm_layer"] = embed_norm_layer
+        try:
+            self.patch_embed = embed_layer(self.image_size, self.patch_size, embed_dim=embed_dim, **embed_args)
+        except TypeError:   # an embed_layer that does not take embed_dim: the reference's call form
+            self.patch_embed = embed_layer(self.image_size, self.patch_size, **embed_args)
+        embed_len = self.patch_embed.num_patches
+
+        # as in the reference (models.py:299) the token exists for any non-None ``class_token`` value
+        self.class_token = None
+        if class_token is not None:
+            self.class_token = nn.Parameter(torch.zeros(1, 1, embed_dim))
+            nn.init.trunc_normal_(self.class_token, std=0.02)
+        pos_embed_len = embed_len + 1 if self.class_token is not None else embed_len
+        self.pos_embed = None
+        if pos_embed == "learn":
+            self.pos_embed = nn.Parameter(torch.zeros(1, pos_embed_len, embed_dim))
+            nn.init.trunc_normal_(self.pos_embed, std=0.02)
+
+        self.norm_pre = norm_layer(embed_dim) if norm_layer else nn.Identity()
+        block_norm = norm_layer if norm_layer else nn.LayerNorm
+        self.blocks = nn.ModuleList([
+            block_fn(embed_dim, num_heads, mlp_ratio, block_norm, act_layer, vit=True) for _ in range(depth)])
+        self.norm_final = final_norm_layer(embed_dim) if final_norm_layer else nn.Identity()
+        self.feature_info = [dict(module=f"block_{i}", num_chs=embed_dim) for i in range(depth)]
+        self.parallel_block = parallel_block
+        self.shard_along_dims = shard_along_dims
+        self._init_weights()
+
+    def _init_weights(self):
+        """Same initialisation law as models.py:338-350."""
+        for m in self.modules():
+            if isinstance(m, nn.Linear):
+                nn.init.xavier_uniform_(m.weight)
+                if m.bias is not None:
+                    nn.init.zeros_(m.bias)
+            elif isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+                if m.bias is not None:
+                    nn.init.zeros_(m.bias)
+            elif isinstance(m, nn.LayerNorm):
+                nn.init.ones_(m.weight)
+                nn.init.zeros_(m.bias)
+
+    def parallelize_blocks(self, device_id, world_size):
+        raise NotImplementedError("DTensor TP/FSDP of ParallelBlock (models.py:363-397) is outside this forward path; "
+                                  "inference is batch-sharded across GPUs with one replica per GPU")
+
+    def spawn_parallel(self, device_id: int, world_size: int, path_to_config: str = "models/sv22b.yaml"):
+        pass  # a no-op in the reference as well (models.py:399-406)
+
+    # ---- HIP path --------------------------------------------------------------------------------
+    def _features2d(self, x: torch.Tensor):
+        """forward_features on the residual-stream buffer: returns (x2d [B*N, ld] bf16, B, N, D)."""
+        pe = self.patch_embed
+        if not isinstance(pe, PatchEmbed) or not pe.flatten:
+            raise NotImplementedError("the HIP path needs this package's PatchEmbed with flatten=True as embed_layer")
+        if self.pos_embed is None:
+            raise TypeError("pos_embed is None: the reference adds it unconditionally (models.py:360)")
+        B = x.shape[0]
+        D, Np = self.embed_dim, pe.num_patches
+        has_cls = self.class_token is not None
+        N = Np + (1 if has_cls else 0)
+        ld = _ops.round_up(D, _ops.k_multiple())
+        alloc = torch.zeros if ld != D else torch.empty
+        x2d = alloc((B * N, ld), dtype=torch.bfloat16, device=x.device)
+        pe._tokens_into(x, x2d, cls_slot=has_cls)
+        en = layernorm_params(pe.norm_layer, "PatchEmbed.norm_layer")
+        npre = layernorm_params(self.norm_pre, "VisionTransformer.norm_pre")
+        f = _ops.f32vec
+        _ops.embed_finalize(
+            x2d, B, N, D, f(self.class_token.reshape(-1)) if has_cls else None, f(self.pos_embed.reshape(N, D)),
+            f(en[0]) if en else None, f(en[1]) if en else None, en[2] if en else 0.0,
+            f(npre[0]) if npre else None, f(npre[1]) if npre else None, npre[2] if npre else 0.0)
+        return x2d, B, N, D
+
+    def _run_blocks(self, x: torch.Tensor):
+        """Everything up to (not including) ``norm_final``; returns (x2d, B, N, D)."""
+        x2d, B, N, D = self._features2d(x)
+        ws = None
+        for blk in self.blocks:
+            if not isinstance(blk, Block):
+                raise NotImplementedError(f"block_fn {type(blk).__name__} has no HIP forward")
+            if ws is None:
+                ws = blk._workspace(B * N, x.device)
+            blk._run(x2d, B, N, ws)
+        return x2d, B, N, D
+
+    def _final_norm(self, x2d: torch.Tensor, B: int, N: int, D: int, like: torch.Tensor) -> torch.Tensor:
+        ln = layernorm_params(self.norm_final, "VisionTransformer.norm_final")
+        if ln is None:
+            return _ops.like_input(x2d[:, :D].reshape(B, N, D), like)
+        out_dtype = torch.float32 if like.dtype == torch.float32 else torch.bfloat16
+        out = torch.empty((B * N, D), dtype=out_dtype, device=x2d.device)
+        _ops.layernorm(x2d, out, B * N, D, _ops.f32vec(ln[0]), _ops.f32vec(ln[1]), ln[2])
+        return out.reshape(B, N, D)
+
+    def forward_features(self, x: torch.Tensor) -> torch.Tensor:
+        """Images (B, C, H, W) -> tokens (B, N, D) entering the first block (models.py:352-361)."""
+        _ops.require_cuda(x, "VisionTransformer.forward_features")
+        with torch.cuda.device(x.device):
+            x2d, B, N, D = self._features2d(x)
+            return _ops.like_input(x2d[:, :D].reshape(B, N, D), x)
+
+    def forward_heads(self, x: torch.Tensor) -> torch.Tensor:
+        """Tokens (B, N, D) -> blocks in order -> ``norm_final`` (models.py:408-411)."""
+        _ops.require_cuda(x, "VisionTransformer.forward_heads")
+        B, N, D = x.shape
+        with torch.cuda.device(x.device):
+            xb, M = _as_rows(x, D)
+            if xb.data_ptr() == x.data_ptr():
+                xb = xb.clone()
+            ws = None
+            for blk in self.blocks:
+                if not isinstance(blk, Block):
+                    raise NotImplementedError(f"block_fn {type(blk).__name__} has no HIP forward")
+                if ws is None:
+                    ws = blk._workspace(M, x.device)
+                blk._run(xb, B, N, ws)
+            return self._final_norm(xb, B, N, D, x)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        """Images (B, C, H, W) -> final-normed token embeddings (B, N, D) (models.py:413-416)."""
+        _ops.require_cuda(x, "VisionTransformer.forward")
+        with torch.cuda.device(x.device):
+            x2d, B, N, D = self._run_blocks(x)
+            return self._final_norm(x2d, B, N, D, x)

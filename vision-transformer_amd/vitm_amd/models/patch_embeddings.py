@@ -1,0 +1,105 @@
+"""Image -> patch tokens on MI355X.
+
+API mirror of the reference's ``PatchEmbed`` (vitm/models/patch_embeddings.py:14-121): same constructor,
+attributes and state_dict keys (``projection.weight`` of shape (D, C, ph, pw), optional ``projection.bias``,
+optional ``norm_layer.{weight,bias}``).  The strided convolution runs as an im2col-fused MFMA GEMM
+(``vitm_patch_embed``); the reference's per-call ``print`` (patch_embeddings.py:112) is not reproduced.
+"""
+from __future__ import annotations
+
+from typing import Callable, Optional, Tuple, Union
+
+import torch
+import torch.nn as nn
+
+from .. import _ops
+from ..utils.helper import Format, nchw_to, to_2tuple
+
+
+def layernorm_params(mod: nn.Module, what: str):
+    """(weight, bias, eps) of an affine nn.LayerNorm, or None for nn.Identity; anything else is refused."""
+    if isinstance(mod, nn.Identity):
+        return None
+    if isinstance(mod, nn.LayerNorm) and mod.elementwise_affine and len(mod.normalized_shape) == 1:
+        return mod.weight, mod.bias, mod.eps
+    raise NotImplementedError(f"{what}: only nn.LayerNorm (affine, last dim) or nn.Identity run on the HIP path, "
+                              f"got {type(mod).__name__}")
+
+
+class PatchEmbed(nn.Module):
+    """Split an image into non-overlapping patches and project each to ``embed_dim``.
+
+    Args mirror patch_embeddings.py:44-54: ``image_size`` (int or (H, W)), ``patch_size``, ``in_channels``,
+    ``embed_dim``, ``norm_layer`` (callable building a norm over embed_dim, or None), ``flatten``
+    ((B, N, D) output when True), ``bias`` (projection bias, default off), ``output_fmt`` (layout used
+    when ``flatten=False``).
+    """
+
+    def __init__(self, image_size: Union[int, Tuple[int, int]] = 224, patch_size: int = 16, in_channels: int = 3,
+                 embed_dim: int = 768, norm_layer: Optional[Callable] = None, flatten: bool = True,
+                 bias: bool = False, output_fmt: Optional[Format] = None):
+        super().__init__()
+        self.output_fmt = output_fmt
+        self.patch_size = to_2tuple(patch_size)
+        self.image_size, self.grid_size, self.num_patches = self._init_img_size(image_size)
+        self.flatten = flatten
+        self.projection = nn.Conv2d(in_channels, embed_dim, kernel_size=self.patch_size, stride=self.patch_size,
+                                    bias=bias)
+        nn.init.kaiming_normal_(self.projection.weight, mode="fan_in", nonlinearity="relu")
+        self.norm_layer = norm_layer(embed_dim) if norm_layer else nn.Identity()
+
+    def _init_img_size(self, image_size):
+        """Resolved (H, W), patches per side [gh, gw] and their product (patch_embeddings.py:71-87)."""
+        image_size = to_2tuple(image_size)
+        grid_size = [s // p for s, p in zip(image_size, self.patch_size)]
+        return image_size, grid_size, grid_size[0] * grid_size[1]
+
+    # ---- HIP path --------------------------------------------------------------------------------
+    def _packed_projection(self) -> _ops.PackedLinear:
+        w, b = self.projection.weight, self.projection.bias
+        return _ops.cached_pack(self, "projection", (w, b), lambda: _ops.pack_linear(w, b))
+
+    def _tokens_into(self, x: torch.Tensor, tokens2d: torch.Tensor, cls_slot: bool) -> None:
+        """Write the projected patch tokens of image batch ``x`` into ``tokens2d`` (rows (b, n), bf16)."""
+        B, C, H, W = x.shape
+        assert self.image_size[0] == H, "Input tensor's height does not match the model"
+        assert self.image_size[1] == W, "Input tensor's width does not match the model"
+        if C != self.projection.in_channels:
+            raise RuntimeError(f"expected {self.projection.in_channels} input channels, got {C}")
+        if x.dtype not in (torch.float32, torch.bfloat16):
+            raise TypeError(f"unsupported image dtype {x.dtype} (bf16 or fp32)")
+        _ops.patch_embed(x.contiguous(), self._packed_projection(), tokens2d, self.patch_size,
+                         self.projection.out_channels, cls_slot)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        """(B, C, H, W) -> (B, N, D) when ``flatten`` else (B, D, gh, gw) / ``output_fmt`` layout."""
+        _ops.require_cuda(x, "PatchEmbed.forward")
+        B, C, H, W = x.shape
+        assert self.image_size[0] == H, "Input tensor's height does not match the model"
+        assert self.image_size[1] == W, "Input tensor's width does not match the model"
+        D, Np = self.projection.out_channels, self.num_patches
+        with torch.cuda.device(x.device):
+            ld = _ops.round_up(D, 8)
+            tok = torch.empty((B * Np, ld), dtype=torch.bfloat16, device=x.device)
+            self._tokens_into(x, tok, cls_slot=False)
+            if self.flatten:
+                ln = layernorm_params(self.norm_layer, "PatchEmbed.norm_layer")
+                if ln is not None:
+                    out = torch.empty_like(tok)
+                    _ops.layernorm(tok, out, B * Np, D, _ops.f32vec(ln[0]), _ops.f32vec(ln[1]), ln[2])
+                    tok = out
+                y = tok[:, :D].reshape(B, Np, D)
+                return _ops.like_input(y, x)
+            # flatten=False: the tokens viewed back as NCHW (a layout view, no arithmetic)
+            y = tok[:, :D].reshape(B, self.grid_size[0], self.grid_size[1], D).permute(0, 3, 1, 2)
+            if self.output_fmt != "NCHW":
+                y = nchw_to(y, self.output_fmt)
+            ln = layernorm_params(self.norm_layer, "PatchEmbed.norm_layer")
+            if ln is not None:
+                if y.shape[-1] != D:
+                    raise RuntimeError(f"norm_layer over {D} features cannot act on a last dim of {y.shape[-1]}")
+                y2 = y.reshape(-1, D).contiguous()
+                out = torch.empty_like(y2)
+                _ops.layernorm(y2, out, y2.shape[0], D, _ops.f32vec(ln[0]), _ops.f32vec(ln[1]), ln[2])
+                y = out.reshape(y.shape)
+            return _ops.like_input(y.contiguous(), x)
