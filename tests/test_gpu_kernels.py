@@ -53,6 +53,42 @@ def test_gemm_bias(ops, M, N, K):
     _close(out, ref, what="gemm bias")
 
 
+@pytest.mark.parametrize("epi", ["bias", "ln", "ln_gelu", "resid", "bias_f32"])
+@pytest.mark.parametrize("M,N,K", [(8200, 2304, 768), (11111, 768, 3072), (9000, 1152, 384), (33000, 3072, 768),
+                                   (16400, 520, 64)])
+def test_gemm_big_tile_kernel(ops, M, N, K, epi):
+    """Shapes large enough to be routed to the 256x256 ping-pong kernel (ragged M and N tails included)."""
+    A = _bf(_rand(M, K, seed=40) * 1.3 + 0.2)
+    W, b = _rand(N, K, seed=41, scale=K ** -0.5), _rand(N, seed=42, scale=0.2)
+    F = torch.nn.functional
+    if epi in ("ln", "ln_gelu"):
+        if K > 2048:
+            pytest.skip("row kernels hold a row in registers: LayerNorm width <= 2048")
+        lw, lb = 1.0 + 0.1 * _rand(K, seed=43), 0.1 * _rand(K, seed=44)
+        pk = ops.pack_linear(W, b, lw, lb)
+        stats = ops.ln_stats(A, M, K, 1e-5)
+        out = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+        ops.gemm(A, pk, out, ops.EPI_LN_GELU if epi == "ln_gelu" else ops.EPI_LN, M, stats=stats)
+        ref = F.layer_norm(A.float(), (K,), lw, lb, 1e-5) @ W.t() + b
+        if epi == "ln_gelu":
+            ref = F.gelu(ref)
+        _close(out, ref, rel=1.5e-2, what=f"big {epi}")
+    elif epi == "resid":
+        gamma = 1.0 + 0.1 * _rand(N, seed=45)
+        x = _bf(_rand(M, N, seed=46))
+        ref = x.float() + gamma * (A.float() @ _bf(W).float().t() + b)
+        pk = ops.pack_linear(W, b, out_scale=gamma)
+        ops.gemm(A, pk, x, ops.EPI_RESIDUAL, M, resid=x)
+        _close(x, ref, what="big resid")
+    else:
+        pk = ops.pack_linear(W, b)
+        dt = torch.float32 if epi == "bias_f32" else torch.bfloat16
+        out = torch.full((M, N), float("nan"), dtype=dt, device=DEV)
+        ops.gemm(A, pk, out, ops.EPI_BIAS, M)
+        ref = A.float() @ _bf(W).float().t() + b
+        _close(out, ref, rel=1e-4 if epi == "bias_f32" else 1e-2, what=f"big {epi}")
+
+
 def test_gemm_identity_asymmetric(ops):
     """A = I against an asymmetric W catches a transposed / permuted fragment map exactly."""
     K = N = 128

@@ -35,8 +35,9 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
-// erf by Abramowitz & Stegun 7.1.26 (|abs err| <= 1.5e-7), enough for fp32-tolerance GELU and far
-// cheaper in an MFMA epilogue than the libm polynomial.
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+
+// erf by Abramowitz & Stegun 7.1.26 (|abs err| <= 1.5e-7): the fp32-accurate form.
 __device__ __forceinline__ float erf_as(float x) {
   const float ax = fabsf(x);
   const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
@@ -49,8 +50,35 @@ __device__ __forceinline__ float erf_as(float x) {
   const float r = fmaf(-p, e, 1.0f);
   return copysignf(r, x);
 }
-__device__ __forceinline__ float gelu_erf(float v) {
+__device__ __forceinline__ float gelu_erf_accurate(float v) {
   return 0.5f * v * (1.0f + erf_as(v * 0.70710678118654752f));
+}
+
+// GELU(x) = x * Phi(x) for bf16 outputs, two values at a time in packed fp32 math (no transcendentals):
+// Phi(x) - 1/2 = xc * Q(xc^2) with xc = clamp(x, -4, 4) and Q a degree-8 minimax polynomial; Phi is shifted by
+// its value at -4 (2.5e-5) and floored at 0 so the negative tail is exactly 0.  |error| <= 2e-5 for |x| <= 4 and
+// <= 2.5e-5 * |x| beyond, far below one bf16 ulp of any output that is not itself below 1e-4.
+__device__ __forceinline__ f32x2_t gelu_erf2(f32x2_t x) {
+  f32x2_t xc;
+  xc.x = __builtin_amdgcn_fmed3f(x.x, -4.0f, 4.0f);
+  xc.y = __builtin_amdgcn_fmed3f(x.y, -4.0f, 4.0f);
+  const f32x2_t t = xc * xc;
+  f32x2_t q = t * 8.065587196e-11f + -7.004855253e-09f;
+  q = q * t + 2.716520232e-07f;
+  q = q * t + -6.295502535e-06f;
+  q = q * t + 9.891200638e-05f;
+  q = q * t + -1.133939351e-03f;
+  q = q * t + 9.877516551e-03f;
+  q = q * t + -6.641063552e-02f;
+  q = q * t + 3.989227214e-01f;
+  f32x2_t phi = xc * q + (0.5f - 2.5e-5f);
+  phi.x = fmaxf(phi.x, 0.0f);
+  phi.y = fmaxf(phi.y, 0.0f);
+  return x * phi;
+}
+__device__ __forceinline__ float gelu_erf(float v) {
+  f32x2_t t = {v, v};
+  return gelu_erf2(t).x;
 }
 
 // ---- host side ------------------------------------------------------------------------------

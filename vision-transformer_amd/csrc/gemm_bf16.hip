@@ -13,9 +13,10 @@
 // fragment reads -- which makes the ds_read_b128 fragment reads bank-conflict free.
 // The accumulators leave through LDS (fp32) so the epilogue runs row-contiguous: 16-byte loads of the
 // residual, 16-byte stores of the output, per-thread column constants.
-#include "common.h"
+#include "gemm_common.h"
 
 namespace {
+using namespace vitm_gemm_detail;
 
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int NTHREADS = 256;
@@ -27,29 +28,6 @@ static_assert(SMEM_BYTES >= 2 * BUF_BYTES, "epilogue staging must cover the doub
 
 enum { A_DIRECT = 0, A_IM2COL_F32 = 1, A_IM2COL_BF16 = 2 };
 
-struct GemmArgs {
-  const bf16_t* A;
-  int64_t lda;
-  const bf16_t* W;
-  int64_t ldw;
-  void* out;
-  int64_t ldo;
-  const float* stats;
-  const float* s;
-  const float* c;
-  const float* g;
-  const bf16_t* resid;
-  int64_t ldr;
-  int M, N, K, tilesN, row_group;
-  // im2col source (patch embedding)
-  const void* img;
-  int C, H, Wd, ph, pw, gw, npatch, kreal, vec;
-};
-
-__device__ __forceinline__ void glds16(const void* g, void* l) {
-  __builtin_amdgcn_global_load_lds(GPTR(g), LPTR(l), 16, 0, 0);
-}
-
 template <int EPI, int AMODE, int OUT_F32>
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -58,14 +36,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const GemmArgs p) {
   const int wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
 
-  // XCD-aware tile order: blocks b and b+8 share an XCD (and its L2); give each XCD a contiguous
-  // run of row-major tiles so the A row panel and the W panels it needs stay in that L2.
-  int wgid;
-  {
-    const int nwg = gridDim.x, bid = blockIdx.x;
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-    wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  }
+  const int wgid = xcd_remap(blockIdx.x, gridDim.x);
   const int m0 = (wgid / p.tilesN) * BM;
   const int n0 = (wgid % p.tilesN) * BN;
 
@@ -223,64 +194,19 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const GemmArgs p) {
   const int cch = tid & 15, rp = tid >> 4;
   const int n = n0 + cch * 8;
   if (n >= p.N) return;
-  float cv[8], sv[8], gv[8];
-  {
-    const float4 c0 = *(const float4*)(p.c + n), c1 = *(const float4*)(p.c + n + 4);
-    cv[0] = c0.x; cv[1] = c0.y; cv[2] = c0.z; cv[3] = c0.w;
-    cv[4] = c1.x; cv[5] = c1.y; cv[6] = c1.z; cv[7] = c1.w;
-    if (EPI == VITM_EPI_LN || EPI == VITM_EPI_LN_GELU) {
-      const float4 s0 = *(const float4*)(p.s + n), s1 = *(const float4*)(p.s + n + 4);
-      sv[0] = s0.x; sv[1] = s0.y; sv[2] = s0.z; sv[3] = s0.w;
-      sv[4] = s1.x; sv[5] = s1.y; sv[6] = s1.z; sv[7] = s1.w;
-    }
-    if (EPI == VITM_EPI_RESIDUAL) {
-      const float4 g0 = *(const float4*)(p.g + n), g1 = *(const float4*)(p.g + n + 4);
-      gv[0] = g0.x; gv[1] = g0.y; gv[2] = g0.z; gv[3] = g0.w;
-      gv[4] = g1.x; gv[5] = g1.y; gv[6] = g1.z; gv[7] = g1.w;
-    }
-  }
+  EpiCols<EPI> cols;
+  cols.load(p, n);
 #pragma unroll
   for (int pass = 0; pass < BM / 16; ++pass) {
     const int row = pass * 16 + rp;
     const int m = m0 + row;
     if (m >= p.M) break;
     float v[8];
-    {
-      const float4 a0 = *(const float4*)(Cs + row * CS_STRIDE + cch * 8);
-      const float4 a1 = *(const float4*)(Cs + row * CS_STRIDE + cch * 8 + 4);
-      v[0] = a0.x; v[1] = a0.y; v[2] = a0.z; v[3] = a0.w;
-      v[4] = a1.x; v[5] = a1.y; v[6] = a1.z; v[7] = a1.w;
-    }
-    if (EPI == VITM_EPI_LN || EPI == VITM_EPI_LN_GELU) {
-      const float2 st = *(const float2*)(p.stats + 2 * (int64_t)m);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = fmaf(st.y, fmaf(-st.x, sv[e], v[e]), cv[e]);
-    } else if (EPI == VITM_EPI_BIAS || EPI == VITM_EPI_BIAS_GELU) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] += cv[e];
-    }
-    if (EPI == VITM_EPI_LN_GELU || EPI == VITM_EPI_BIAS_GELU) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e]);
-    }
-    if (EPI == VITM_EPI_RESIDUAL) {
-      const u16x8_t rv = *(const u16x8_t*)(p.resid + (int64_t)m * p.ldr + n);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = bf2f(rv[e]) + fmaf(gv[e], v[e], cv[e]);
-    }
-    const int64_t om = p.row_group > 0 ? (int64_t)m + m / p.row_group + 1 : (int64_t)m;
-    if (OUT_F32) {
-      float* o = (float*)p.out + om * p.ldo + n;
-      *(float4*)o = make_float4(v[0], v[1], v[2], v[3]);
-      *(float4*)(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
-    } else {
-      uint4 o;
-      o.x = pack_bf2(v[0], v[1]);
-      o.y = pack_bf2(v[2], v[3]);
-      o.z = pack_bf2(v[4], v[5]);
-      o.w = pack_bf2(v[6], v[7]);
-      *(uint4*)((bf16_t*)p.out + om * p.ldo + n) = o;
-    }
+    const float4 a0 = *(const float4*)(Cs + row * CS_STRIDE + cch * 8);
+    const float4 a1 = *(const float4*)(Cs + row * CS_STRIDE + cch * 8 + 4);
+    v[0] = a0.x; v[1] = a0.y; v[2] = a0.z; v[3] = a0.w;
+    v[4] = a1.x; v[5] = a1.y; v[6] = a1.z; v[7] = a1.w;
+    cols.template finish<OUT_F32>(p, m, n, v);
   }
 }
 
@@ -352,6 +278,7 @@ extern "C" int vitm_gemm(const void* A, int64_t lda, const void* Wp, int64_t ldw
   a.out = out; a.ldo = ldo; a.stats = stats; a.s = s; a.c = c; a.g = g;
   a.resid = (const bf16_t*)resid; a.ldr = ldr;
   a.M = M; a.N = N; a.K = K; a.tilesN = (N + BN - 1) / BN; a.row_group = row_group;
+  if (vitm_gemm_pp_wanted(M, N, K)) return vitm_gemm_pp_launch(a, epilogue, out_dtype == VITM_F32, (hipStream_t)stream);
   return dispatch<A_DIRECT>(a, epilogue, out_dtype == VITM_F32, (hipStream_t)stream);
 }
 

@@ -1,0 +1,107 @@
+// Argument block and helpers shared by the GEMM kernels of libvitm_gfx950.
+#pragma once
+#include "common.h"
+
+namespace vitm_gemm_detail {
+
+struct GemmArgs {
+  const bf16_t* A;
+  int64_t lda;
+  const bf16_t* W;
+  int64_t ldw;
+  void* out;
+  int64_t ldo;
+  const float* stats;
+  const float* s;
+  const float* c;
+  const float* g;
+  const bf16_t* resid;
+  int64_t ldr;
+  int M, N, K, tilesN, row_group;
+  // im2col source (patch embedding)
+  const void* img;
+  int C, H, Wd, ph, pw, gw, npatch, kreal, vec;
+};
+
+__device__ __forceinline__ void glds16(const void* g, void* l) {
+  __builtin_amdgcn_global_load_lds(GPTR(g), LPTR(l), 16, 0, 0);
+}
+
+// XCD-aware tile order: blocks b and b+8 share an XCD (and its L2); give each XCD a contiguous run of
+// row-major tiles so the A row panel and the W panels it needs stay in that L2.  Bijective for any grid.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+// Per-thread column constants of the row-contiguous epilogue (8 consecutive output columns).
+template <int EPI>
+struct EpiCols {
+  float cv[8], sv[8], gv[8];
+  __device__ __forceinline__ void load(const GemmArgs& p, int n) {
+    const float4 c0 = *(const float4*)(p.c + n), c1 = *(const float4*)(p.c + n + 4);
+    cv[0] = c0.x; cv[1] = c0.y; cv[2] = c0.z; cv[3] = c0.w;
+    cv[4] = c1.x; cv[5] = c1.y; cv[6] = c1.z; cv[7] = c1.w;
+    if (EPI == VITM_EPI_LN || EPI == VITM_EPI_LN_GELU) {
+      const float4 s0 = *(const float4*)(p.s + n), s1 = *(const float4*)(p.s + n + 4);
+      sv[0] = s0.x; sv[1] = s0.y; sv[2] = s0.z; sv[3] = s0.w;
+      sv[4] = s1.x; sv[5] = s1.y; sv[6] = s1.z; sv[7] = s1.w;
+    }
+    if (EPI == VITM_EPI_RESIDUAL) {
+      const float4 g0 = *(const float4*)(p.g + n), g1 = *(const float4*)(p.g + n + 4);
+      gv[0] = g0.x; gv[1] = g0.y; gv[2] = g0.z; gv[3] = g0.w;
+      gv[4] = g1.x; gv[5] = g1.y; gv[6] = g1.z; gv[7] = g1.w;
+    }
+  }
+  // v[8] = fp32 accumulators of row m, columns n..n+7 -> fixed up and stored
+  template <int OUT_F32>
+  __device__ __forceinline__ void finish(const GemmArgs& p, int m, int n, float* v) const {
+    u16x8_t rv = {0, 0, 0, 0, 0, 0, 0, 0};
+    float2 st = make_float2(0.f, 1.f);
+    if (EPI == VITM_EPI_RESIDUAL) rv = *(const u16x8_t*)(p.resid + (int64_t)m * p.ldr + n);
+    if (EPI == VITM_EPI_LN || EPI == VITM_EPI_LN_GELU) st = *(const float2*)(p.stats + 2 * (int64_t)m);
+    finish_pre<OUT_F32>(p, m, n, v, rv, st);
+  }
+  // same with the row's residual values / LayerNorm statistics already in registers
+  template <int OUT_F32>
+  __device__ __forceinline__ void finish_pre(const GemmArgs& p, int m, int n, float* v, u16x8_t rv, float2 st) const {
+    if (EPI == VITM_EPI_LN || EPI == VITM_EPI_LN_GELU) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = fmaf(st.y, fmaf(-st.x, sv[e], v[e]), cv[e]);
+    } else if (EPI == VITM_EPI_BIAS || EPI == VITM_EPI_BIAS_GELU) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] += cv[e];
+    }
+    if (EPI == VITM_EPI_LN_GELU || EPI == VITM_EPI_BIAS_GELU) {
+#pragma unroll
+      for (int e = 0; e < 8; e += 2) {
+        const f32x2_t gl = gelu_erf2((f32x2_t){v[e], v[e + 1]});
+        v[e] = gl.x;
+        v[e + 1] = gl.y;
+      }
+    }
+    if (EPI == VITM_EPI_RESIDUAL) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = bf2f(rv[e]) + fmaf(gv[e], v[e], cv[e]);
+    }
+    const int64_t om = p.row_group > 0 ? (int64_t)m + m / p.row_group + 1 : (int64_t)m;
+    if (OUT_F32) {
+      float* o = (float*)p.out + om * p.ldo + n;
+      *(float4*)o = make_float4(v[0], v[1], v[2], v[3]);
+      *(float4*)(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    } else {
+      uint4 o;
+      o.x = pack_bf2(v[0], v[1]);
+      o.y = pack_bf2(v[2], v[3]);
+      o.z = pack_bf2(v[4], v[5]);
+      o.w = pack_bf2(v[6], v[7]);
+      *(uint4*)((bf16_t*)p.out + om * p.ldo + n) = o;
+    }
+  }
+};
+
+}  // namespace vitm_gemm_detail
+
+// big-tile kernel (gemm_pp.hip); returns VITM_EUNSUPPORTED-free status, assumes validated arguments
+int vitm_gemm_pp_launch(const vitm_gemm_detail::GemmArgs& a, int epilogue, int out_f32, hipStream_t st);
+bool vitm_gemm_pp_wanted(int M, int N, int K);
