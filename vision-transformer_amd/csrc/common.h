@@ -25,8 +25,12 @@ __device__ __forceinline__ float bf2f(bf16_t u) {
 __device__ __forceinline__ bf16_t f2bf(float f) {
   return __builtin_bit_cast(bf16_t, (__bf16)f);
 }
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+// two fp32 -> one dword of two bf16 (lo in bits 0-15), a single v_cvt_pk_bf16_f32
 __device__ __forceinline__ unsigned pack_bf2(float lo, float hi) {
-  return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+  const f32x2_t v = {lo, hi};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
 }
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -34,8 +38,6 @@ __device__ __forceinline__ float wave_sum(float v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
-
-typedef __attribute__((ext_vector_type(2))) float f32x2_t;
 
 // erf by Abramowitz & Stegun 7.1.26 (|abs err| <= 1.5e-7): the fp32-accurate form.
 __device__ __forceinline__ float erf_as(float x) {
@@ -75,6 +77,32 @@ __device__ __forceinline__ f32x2_t gelu_erf2(f32x2_t x) {
   phi.x = fmaxf(phi.x, 0.0f);
   phi.y = fmaxf(phi.y, 0.0f);
   return x * phi;
+}
+// the same function on NP independent pairs with the Horner steps interleaved across pairs (one dependent chain
+// per pair would leave the packed-math pipe waiting on itself)
+template <int NP>
+__device__ __forceinline__ void gelu_erf2_n(f32x2_t* x) {
+  f32x2_t xc[NP], t[NP], q[NP];
+#pragma unroll
+  for (int k = 0; k < NP; ++k) {
+    xc[k].x = __builtin_amdgcn_fmed3f(x[k].x, -4.0f, 4.0f);
+    xc[k].y = __builtin_amdgcn_fmed3f(x[k].y, -4.0f, 4.0f);
+    t[k] = xc[k] * xc[k];
+    q[k] = t[k] * 8.065587196e-11f + -7.004855253e-09f;
+  }
+  const float cf[7] = {2.716520232e-07f, -6.295502535e-06f, 9.891200638e-05f, -1.133939351e-03f,
+                       9.877516551e-03f, -6.641063552e-02f, 3.989227214e-01f};
+#pragma unroll
+  for (int c = 0; c < 7; ++c)
+#pragma unroll
+    for (int k = 0; k < NP; ++k) q[k] = q[k] * t[k] + cf[c];
+#pragma unroll
+  for (int k = 0; k < NP; ++k) {
+    f32x2_t phi = xc[k] * q[k] + (0.5f - 2.5e-5f);
+    phi.x = fmaxf(phi.x, 0.0f);
+    phi.y = fmaxf(phi.y, 0.0f);
+    x[k] = x[k] * phi;
+  }
 }
 __device__ __forceinline__ float gelu_erf(float v) {
   f32x2_t t = {v, v};

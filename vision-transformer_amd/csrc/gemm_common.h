@@ -67,7 +67,7 @@ struct EpiCols {
   __device__ __forceinline__ void finish_pre(const GemmArgs& p, int m, int n, float* v, u16x8_t rv, float2 st) const {
     if (EPI == VITM_EPI_LN || EPI == VITM_EPI_LN_GELU) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = fmaf(st.y, fmaf(-st.x, sv[e], v[e]), cv[e]);
+      for (int e = 0; e < 8; ++e) v[e] = fmaf(fmaf(-sv[e], st.x, v[e]), st.y, cv[e]);  // rstd * (acc - mean * s) + c
     } else if (EPI == VITM_EPI_BIAS || EPI == VITM_EPI_BIAS_GELU) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] += cv[e];

@@ -31,16 +31,28 @@
 #define PP_ABLATE 0   // timing-only diagnostic builds (wrong results): 1 no DMA in the loop, 2 no fragment reads, 4 no output stores
 #endif
 
+#ifdef PP_STAMP  // diagnostic build: wave 0 of each workgroup records s_memtime at phase boundaries into p.resid
+#define STAMP(k)                                                                                   \
+  do {                                                                                             \
+    unsigned long long t__;                                                                        \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__)::"memory");                    \
+    if (tid == 0) ((unsigned long long*)p.resid)[(size_t)blockIdx.x * 8 + (k)] = t__;              \
+  } while (0)
+#else
+#define STAMP(k) do {} while (0)
+#endif
+
 namespace {
 using namespace vitm_gemm_detail;
 
 constexpr int BM = 256, BN = 256, BK = 64;
 constexpr int NT = 512;
-constexpr int PART = 256 * 128;             // bytes of the A (or W) part of a slot
-constexpr int SLOT = 2 * PART;              // 64 KiB
+constexpr int PART = 256 * 128;             // bytes of one operand tile: 256 rows x 128 B
+constexpr int NA = 3, NW = 2;               // LDS ring depth: A tiles (HBM / Infinity Cache latency), W tiles (L2)
+constexpr int WBASE = NA * PART;            // W tiles follow the A tiles
 constexpr int CS = BN + 4;                  // fp32 staging row stride (floats)
-constexpr int SMEM = 256 * 528;             // 135168 B: bf16 tile image of the epilogue
-static_assert(SMEM >= 2 * SLOT && SMEM >= 128 * CS * 4, "epilogue staging must fit");
+constexpr int SMEM = (NA + NW) * PART;      // 163840 B = all of a CU's LDS
+static_assert(SMEM >= 256 * 528 && SMEM >= 128 * CS * 4 && SMEM <= 160 * 1024, "epilogue staging must fit");
 
 __device__ __forceinline__ void seg_barrier() {
   asm volatile("" ::: "memory");
@@ -79,12 +91,12 @@ __global__ __launch_bounds__(NT, 2) void gemm_pp_kernel(const GemmArgs p) {
     wsrc[q] = p.W + (int64_t)wn * p.ldw + lc * 8;
   }
   auto issueA = [&](int t) {
-    char* sb = smem + (t & 1) * SLOT + 4 * wave * 1024;
+    char* sb = smem + (t % NA) * PART + 4 * wave * 1024;
 #pragma unroll
     for (int q = 0; q < 4; ++q) glds16(asrc[q] + t * BK, sb + q * 1024);
   };
   auto issueW = [&](int t) {
-    char* sb = smem + (t & 1) * SLOT + PART + 4 * wave * 1024;
+    char* sb = smem + WBASE + (t & 1) * PART + 4 * wave * 1024;
 #pragma unroll
     for (int q = 0; q < 4; ++q) glds16(wsrc[q] + t * BK, sb + q * 1024);
   };
@@ -95,7 +107,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_pp_kernel(const GemmArgs p) {
   for (int kk = 0; kk < 2; ++kk) {
     const int pch = ((kk * 4 + (lane >> 4)) ^ (lane & 7)) * 16;
     offA[kk] = (grp * 128 + (lane & 15)) * 128 + pch;
-    offB[kk] = PART + (wc * 64 + (lane & 15)) * 128 + pch;
+    offB[kk] = WBASE + (wc * 64 + (lane & 15)) * 128 + pch;
   }
 
   f32x4_t acc[8][4];
@@ -107,11 +119,12 @@ __global__ __launch_bounds__(NT, 2) void gemm_pp_kernel(const GemmArgs p) {
   bf16x8_t a[8], b[4];
   auto load_frags = [&](int t, int kk) {
     if ((PP_ABLATE & 2) && (t | kk)) return;
-    const char* sb = smem + (t & 1) * SLOT;
+    const char* sa = smem + (t % NA) * PART;
+    const char* sw = smem + (t & 1) * PART;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) b[j] = *(const bf16x8_t*)(sb + offB[kk] + j * 2048);
+    for (int j = 0; j < 4; ++j) b[j] = *(const bf16x8_t*)(sw + offB[kk] + j * 2048);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) a[i] = *(const bf16x8_t*)(sb + offA[kk] + i * 2048);
+    for (int i = 0; i < 8; ++i) a[i] = *(const bf16x8_t*)(sa + offA[kk] + i * 2048);
   };
   // the weight tile is the MFMA A operand: a lane ends up with 4 consecutive output COLUMNS of one output row
   auto compute = [&]() {
@@ -129,55 +142,60 @@ __global__ __launch_bounds__(NT, 2) void gemm_pp_kernel(const GemmArgs p) {
   const int nk = p.K / BK;
   const bool dma = (PP_ABLATE & 1) == 0;
 
-  // ---- prologue: K-tiles 0 and 1 in flight, K-tile 0 landed and published
+  STAMP(0);
+  // ---- prologue.  Issue order is what makes the counted waits work (vmcnt retires in order): A(0) W(0) A(1),
+  // then per K-tile t: W(t+1) in the wave's L(t,0), A(t+2) in its L(t,1); "vmcnt(4)" at the end of segment 3 leaves the 4
+  // pieces of A(t+2) in flight and guarantees A(t+1), W(t+1) and everything older have landed.
   issueA(0);
   issueW(0);
   if (nk > 1) {
     issueA(1);
-    issueW(1);
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
   } else {
     wait_dma_all();
   }
   seg_barrier();
+  STAMP(1);
 
+  // DMA is issued only from LOAD segments: a piece blocks its wave for 60-180 cycles while the address unit takes
+  // it, which inside a COMPUTE segment would stall the matrix pipe directly.
   if (grp == 0) {
     for (int t = 0; t < nk; ++t) {
-      const bool pre = dma && t >= 1 && t + 1 < nk;
-      if (pre) issueA(t + 1);          // segment 0
       load_frags(t, 0);
+      if (dma && t + 1 < nk && !(PP_ABLATE & 8)) issueW(t + 1);    // segment 0: L(t,0)
       wait_lds();
       seg_barrier();
-      if (pre) issueW(t + 1);          // segment 1
-      compute();
+      compute();                                                   // segment 1: C(t,0)
       seg_barrier();
-      load_frags(t, 1);                // segment 2
+      load_frags(t, 1);
+      if (dma && t + 2 < nk && !(PP_ABLATE & 16)) issueA(t + 2);   // segment 2: L(t,1)
       wait_lds();
       seg_barrier();
-      compute();                       // segment 3
-      wait_dma_all();
+      compute();                                                   // segment 3: C(t,1)
+      if (t + 2 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else wait_dma_all();
       seg_barrier();
     }
     seg_barrier();                     // group 1's last COMPUTE
   } else {
     seg_barrier();                     // group 0's first LOAD
     for (int t = 0; t < nk; ++t) {
-      if (dma && t >= 1 && t + 1 < nk) issueW(t + 1);   // segment 1
       load_frags(t, 0);
+      if (dma && t + 1 < nk && !(PP_ABLATE & 8)) issueW(t + 1);    // segment 1: L(t,0)
       wait_lds();
       seg_barrier();
-      compute();                       // segment 2
+      compute();                                                   // segment 2: C(t,0)
       seg_barrier();
-      load_frags(t, 1);                // segment 3
+      load_frags(t, 1);
+      if (dma && t + 2 < nk && !(PP_ABLATE & 16)) issueA(t + 2);   // segment 3: L(t,1)
       wait_lds();
-      wait_dma_all();
+      if (t + 2 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else wait_dma_all();
       seg_barrier();
-      if (dma && t + 2 < nk) issueA(t + 2);             // segment 0 of the next K-tile
-      compute();
+      compute();                                                   // segment 0 of K-tile t+1: C(t,1)
       seg_barrier();
     }
   }
 
+  STAMP(2);
   // ---- epilogue.  The MFMAs ran with the weight tile as the A operand, so a lane holds, for each (i, j),
   // 4 CONSECUTIVE output columns of one output row:
   //   acc[i][j][r] = out[m0 + 128 grp + 16 i + (lane & 15)][n0 + 64 wc + 16 j + 4 (lane >> 4) + r]
@@ -204,30 +222,33 @@ __global__ __launch_bounds__(NT, 2) void gemm_pp_kernel(const GemmArgs p) {
         m = m < p.M ? m : p.M - 1;
         st = *(const float2*)(p.stats + 2 * (int64_t)m);
       }
+      f32x2_t v[8];  // the 16 values of row i: pairs (j, half)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-        const float cv[4] = {cq[j].x, cq[j].y, cq[j].z, cq[j].w};
+        const f32x2_t c01 = {cq[j].x, cq[j].y}, c23 = {cq[j].z, cq[j].w};
+        v[2 * j] = (f32x2_t){acc[i][j][0], acc[i][j][1]};
+        v[2 * j + 1] = (f32x2_t){acc[i][j][2], acc[i][j][3]};
         if (EPI == VITM_EPI_LN || EPI == VITM_EPI_LN_GELU) {
-          const float sv[4] = {sq[j].x, sq[j].y, sq[j].z, sq[j].w};
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = fmaf(st.y, fmaf(-st.x, sv[e], v[e]), cv[e]);
+          const f32x2_t s01 = {sq[j].x, sq[j].y}, s23 = {sq[j].z, sq[j].w};
+          v[2 * j] = (v[2 * j] - s01 * st.x) * st.y + c01;       // rstd * (acc - mean * s) + c
+          v[2 * j + 1] = (v[2 * j + 1] - s23 * st.x) * st.y + c23;
         } else {
+          v[2 * j] += c01;
+          v[2 * j + 1] += c23;
+        }
+      }
+      if (EPI == VITM_EPI_LN_GELU || EPI == VITM_EPI_BIAS_GELU) gelu_erf2_n<8>(v);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] += cv[e];
-        }
-        if (EPI == VITM_EPI_LN_GELU || EPI == VITM_EPI_BIAS_GELU) {
-          const f32x2_t g0 = gelu_erf2((f32x2_t){v[0], v[1]}), g1 = gelu_erf2((f32x2_t){v[2], v[3]});
-          v[0] = g0.x; v[1] = g0.y; v[2] = g1.x; v[3] = g1.y;
-        }
+      for (int j = 0; j < 4; ++j) {
         uint2 w;
-        w.x = pack_bf2(v[0], v[1]);
-        w.y = pack_bf2(v[2], v[3]);
+        w.x = pack_bf2(v[2 * j].x, v[2 * j].y);
+        w.y = pack_bf2(v[2 * j + 1].x, v[2 * j + 1].y);
         *(uint2*)(smem + (mrow + 16 * i) * TS + (ncol + 16 * j) * 2) = w;
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     seg_barrier();
+    STAMP(3);
     const int ch = tid & 31, rp = tid >> 5;   // 16-byte chunk of the row, row within a 16-row pass
     const int n = n0 + ch * 8;
     if (n < p.N && (PP_ABLATE & 4) == 0) {
@@ -238,11 +259,15 @@ __global__ __launch_bounds__(NT, 2) void gemm_pp_kernel(const GemmArgs p) {
         const int m = m0 + row;
         if (m < p.M) {
           const uint4 w = *(const uint4*)(smem + row * TS + ch * 16);
-          const int64_t om = p.row_group > 0 ? (int64_t)m + m / p.row_group + 1 : (int64_t)m;
-          *(uint4*)(obase + om * p.ldo) = w;
+          *(uint4*)(obase + (int64_t)m * p.ldo) = w;
         }
       }
     }
+    STAMP(4);
+#ifdef PP_STAMP
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    STAMP(5);
+#endif
     return;
   }
 
