@@ -278,7 +278,7 @@ extern "C" int vitm_gemm(const void* A, int64_t lda, const void* Wp, int64_t ldw
   a.out = out; a.ldo = ldo; a.stats = stats; a.s = s; a.c = c; a.g = g;
   a.resid = (const bf16_t*)resid; a.ldr = ldr;
   a.M = M; a.N = N; a.K = K; a.tilesN = (N + BN - 1) / BN; a.row_group = row_group;
-  if (row_group == 0 && vitm_gemm_pp_wanted(M, N, K)) return vitm_gemm_pp_launch(a, epilogue, out_dtype == VITM_F32, (hipStream_t)stream);
+  if (row_group == 0 && out_dtype == VITM_BF16 && vitm_gemm_pp_wanted(M, N, K)) return vitm_gemm_pp_launch(a, epilogue, (hipStream_t)stream);
   return dispatch<A_DIRECT>(a, epilogue, out_dtype == VITM_F32, (hipStream_t)stream);
 }
 

@@ -17,7 +17,7 @@ struct GemmArgs {
   const float* g;
   const bf16_t* resid;
   int64_t ldr;
-  int M, N, K, tilesN, row_group;
+  int M, N, K, tilesM, tilesN, row_group;
   // im2col source (patch embedding)
   const void* img;
   int C, H, Wd, ph, pw, gw, npatch, kreal, vec;
@@ -102,6 +102,6 @@ struct EpiCols {
 
 }  // namespace vitm_gemm_detail
 
-// big-tile kernel (gemm_pp.hip); returns VITM_EUNSUPPORTED-free status, assumes validated arguments
-int vitm_gemm_pp_launch(const vitm_gemm_detail::GemmArgs& a, int epilogue, int out_f32, hipStream_t st);
+// big-tile persistent kernel (gemm_pp.hip): bf16 output, row_group == 0, arguments already validated
+int vitm_gemm_pp_launch(const vitm_gemm_detail::GemmArgs& a, int epilogue, hipStream_t st);
 bool vitm_gemm_pp_wanted(int M, int N, int K);

@@ -1,42 +1,55 @@
-// Big-tile bf16 MFMA GEMM for gfx950 with a two-group ping-pong schedule:  out = epilogue(A[M,K] . Wp[N,K]^T)
+// Big-tile bf16 MFMA GEMM for gfx950, persistent, with a two-group ping-pong schedule:
+//     out = epilogue(A[M,K] . Wp[N,K]^T)
 //
-// Tile 256x256, K-tile 64, 512 threads = 8 waves, one workgroup per CU.  Waves 0-3 (group 0) own output rows
-// 0-127, waves 4-7 (group 1) rows 128-255; wave (g, c) computes the 128x64 block at columns 64c: 8x4 MFMA
-// 16x16x32 tiles = 128 accumulator registers.  A K-tile is consumed in two 32-deep sub-steps; per sub-step a
-// wave has a LOAD segment (12 ds_read_b128 operand fragments -> registers) and a COMPUTE segment (32
-// back-to-back MFMAs on those registers).  Each SIMD hosts one wave of each group and the groups run one
-// segment apart, so the matrix pipe of every SIMD always has one wave feeding it while the other does its
-// memory work:
+// One 512-thread workgroup (8 waves) per CU walks a list of 256x256 output tiles.  Waves 0-3 (group 0) own output
+// rows 0-127 of the tile, waves 4-7 (group 1) rows 128-255; wave (g, c) computes the 128x64 block at columns 64c:
+// 8x4 MFMA 16x16x32 tiles = 128 accumulator registers.  K is consumed in 64-deep K-tiles, each in two 32-deep
+// sub-steps; per sub-step a wave has a LOAD segment (12 ds_read_b128 operand fragments -> registers, plus its
+// share of the LDS-DMA for later K-tiles) and a COMPUTE segment (32 back-to-back MFMAs on those registers).
+// Each SIMD hosts one wave of each group and the groups run one segment apart, so the matrix pipe of every SIMD
+// always has one wave feeding it while the other wave does its memory work:
 //
 //     segment (mod 4):    0          1          2          3          0
 //     group 0:        | L(t,0)   | C(t,0)   | L(t,1)   | C(t,1)   | L(t+1,0) ...
 //     group 1:        | C(t-1,1) | L(t,0)   | C(t,0)   | L(t,1)   | C(t,1)   ...
 //
-// Segments are separated by raw s_barrier; group 1 idles through segment 0 and group 0 through the last one.
+// Segments are separated by raw s_barrier.  At the start of a tile group 1 waits one barrier (group 0's first
+// LOAD) and at its end group 0 waits one (group 1's last COMPUTE); both groups then run the epilogue together.
 //
-// LDS holds two K-tile slots (A part 256 rows x 128 B, W part 256 rows x 128 B = 64 KiB per slot).  Operands
-// come global -> LDS by LDS-DMA in 1-KiB pieces of 8 rows x 128 B: whole cache lines, half as many address-unit
-// cycles as 16 x 64 B pieces.  Slot (t+1)&1 is free once group 1 has read L(t-1,1), i.e. after segment 3 of
-// K-tile t-1; every wave then issues its A pieces of K-tile t+1 in segment 0 and its W pieces in segment 1 (inside
-// whatever role it has there), and retires them with s_waitcnt vmcnt(0) at the end of segment 3, three to four
-// segments (1500-2000 MFMA cycles) later; the barrier closing segment 3 publishes them just before group 0
-// starts L(t+1,0).  No wait for DMA sits on the critical path in steady state.
+// Operands go global -> LDS by LDS-DMA in 1-KiB pieces of 8 rows x 128 B (whole cache lines).  LDS holds a ring
+// of 3 A tiles and 2 W tiles (256 rows x 128 B = 32 KiB each, 160 KiB in all); activations come from HBM / the
+// Infinity Cache and get the deeper ring, weights sit in L2.  The K-tile stream runs straight across tile
+// boundaries: while a tile's last K-tiles are being multiplied, the first K-tiles of the NEXT tile of this
+// workgroup are already landing, and since the epilogue touches no LDS there is no prologue bubble between tiles.
+// A piece blocks its wave for 60-180 cycles while the address unit takes it, so DMA is issued only from LOAD
+// segments (never between MFMAs).  vmcnt retires in order, so the issue order is A(0) W(0) A(1), then per K-tile
+// g: W(g+1) in L(g,0) and A(g+2) in L(g,1); "s_waitcnt vmcnt(4)" at the end of segment 3 leaves the 4 pieces of
+// A(g+2) in flight and guarantees A(g+1), W(g+1) and everything older (output stores included) are done; the
+// barrier closing segment 3 publishes them just before group 0 starts L(g+1,0).  Weights are in flight for ~4
+// segments, activations for ~6 (about 3000 MFMA cycles).
 //
 // 128-byte LDS rows: the 16-byte chunk index is XOR-ed with (row & 7), on the DMA's per-lane SOURCE address (its
 // LDS destination is lane-linear) and on the fragment reads; every ds_read_b128 lane group then hits 16 distinct
 // 16-byte bank slots.
+//
+// Epilogue, in registers only.  The weight tile is the MFMA A operand, so a lane holds 4 consecutive output
+// COLUMNS of one output row per accumulator tile; bias / folded-LayerNorm fix-up / GELU / LayerScale run on the
+// fp32 accumulators in place, v_permlane16_swap pairs the quads of two neighbouring column tiles into 8
+// consecutive columns per lane, a DPP row rotate pairs rows r and r+8, and each store instruction then writes 8 rows
+// x 128 contiguous bytes (whole cache lines: 16 rows x 64 bytes measured 3x slower to drain).  Stores are never
+// waited for inside the tile that issued them.
 #include "gemm_common.h"
 
 #ifndef PP_ABLATE
-#define PP_ABLATE 0   // timing-only diagnostic builds (wrong results): 1 no DMA in the loop, 2 no fragment reads, 4 no output stores
+#define PP_ABLATE 0   // timing-only diagnostic builds (wrong results): 1 no DMA after the prologue, 4 no output stores
 #endif
 
-#ifdef PP_STAMP  // diagnostic build: wave 0 of each workgroup records s_memtime at phase boundaries into p.resid
+#ifdef PP_STAMP  // diagnostic build: thread 0 of each workgroup records s_memtime at phase boundaries into p.resid
 #define STAMP(k)                                                                                   \
   do {                                                                                             \
     unsigned long long t__;                                                                        \
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__)::"memory");                    \
-    if (tid == 0) ((unsigned long long*)p.resid)[(size_t)blockIdx.x * 8 + (k)] = t__;              \
+    if (tid == 0 && it < 12 && p.resid) ((unsigned long long*)p.resid)[((size_t)blockIdx.x * 12 + it) * 4 + (k)] = t__; \
   } while (0)
 #else
 #define STAMP(k) do {} while (0)
@@ -48,11 +61,46 @@ using namespace vitm_gemm_detail;
 constexpr int BM = 256, BN = 256, BK = 64;
 constexpr int NT = 512;
 constexpr int PART = 256 * 128;             // bytes of one operand tile: 256 rows x 128 B
-constexpr int NA = 3, NW = 2;               // LDS ring depth: A tiles (HBM / Infinity Cache latency), W tiles (L2)
+constexpr int NA = 3;                       // LDS ring depth of A tiles; W tiles: 2
 constexpr int WBASE = NA * PART;            // W tiles follow the A tiles
-constexpr int CS = BN + 4;                  // fp32 staging row stride (floats)
-constexpr int SMEM = (NA + NW) * PART;      // 163840 B = all of a CU's LDS
-static_assert(SMEM >= 256 * 528 && SMEM >= 128 * CS * 4 && SMEM <= 160 * 1024, "epilogue staging must fit");
+constexpr int SMEM = (NA + 2) * PART;       // 163840 B = all of a CU's LDS
+static_assert(SMEM <= 160 * 1024, "LDS budget");
+
+// v_permlane16_swap: lanes 16-31 / 48-63 of `a` trade places with lanes 0-15 / 32-47 of `b`.  Afterwards a lane of
+// an even 16-lane row holds (its own a, the a of lane+16) and a lane of an odd row (the b of lane-16, its own b).
+// Inline asm on purpose: with float operands hipcc (ROCm 7.2) folds the builtin's second result into the first.
+// The two v_nop are the wait states the instruction needs after a VALU write of its operands.
+__device__ __forceinline__ void swap16(unsigned& a, unsigned& b) {
+  asm volatile("v_nop\n\tv_nop\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ void swap16(float& a, float& b) {
+  asm volatile("v_nop\n\tv_nop\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+
+// Lanes l and l^8 (output rows r and r+8 of a 16-row accumulator tile) trade 16-byte chunks so that one store
+// instruction covers 8 rows x 128 contiguous bytes (whole cache lines) instead of 16 rows x 64 bytes.  In: x0 / x1
+// = this lane's row, columns [c, c+8) / [c+32, c+40).  Out: x0 goes to row (r&7) and x1 to row 8+(r&7), both at
+// columns c + (r >= 8 ? 32 : 0).
+__device__ __forceinline__ void rowpair_exchange1(unsigned& x0, unsigned& x1, bool hi8) {
+  const unsigned t = hi8 ? x0 : x1;
+  const unsigned r = __builtin_amdgcn_update_dpp(0u, t, 0x128, 0xf, 0xf, false);   // row_ror:8 -> value of lane ^ 8
+  const unsigned a = hi8 ? r : x0, b = hi8 ? x1 : r;
+  x0 = a;
+  x1 = b;
+}
+__device__ __forceinline__ void rowpair_exchange(uint4& x0, uint4& x1, bool hi8) {
+  rowpair_exchange1(x0.x, x1.x, hi8);
+  rowpair_exchange1(x0.y, x1.y, hi8);
+  rowpair_exchange1(x0.z, x1.z, hi8);
+  rowpair_exchange1(x0.w, x1.w, hi8);
+}
+
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+// 16-byte non-temporal store of an output chunk: the output (hundreds of MB) is not read again by this kernel, and
+// written with the default policy it pushes the weight tiles out of L2 (measured: +7..9 % on the K = 768 shapes)
+__device__ __forceinline__ void store_out(void* ptr, unsigned a, unsigned b, unsigned c, unsigned d) {
+  __builtin_nontemporal_store((u32x4_t){a, b, c, d}, (u32x4_t*)ptr);
+}
 
 __device__ __forceinline__ void seg_barrier() {
   asm volatile("" ::: "memory");
@@ -60,9 +108,13 @@ __device__ __forceinline__ void seg_barrier() {
   asm volatile("" ::: "memory");
 }
 __device__ __forceinline__ void wait_lds() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
-__device__ __forceinline__ void wait_dma_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// all DMA of this wave landed except, when `keep4`, its 4 youngest pieces
+__device__ __forceinline__ void wait_dma(bool keep4) {
+  if (keep4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
 
-template <int EPI, int OUT_F32>
+template <int EPI>
 __global__ __launch_bounds__(NT, 2) void gemm_pp_kernel(const GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -70,38 +122,78 @@ __global__ __launch_bounds__(NT, 2) void gemm_pp_kernel(const GemmArgs p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int grp = wave >> 2, wc = wave & 3;
 
-  const int wgid = xcd_remap(blockIdx.x, gridDim.x);
-  const int m0 = (wgid / p.tilesN) * BM;
-  const int n0 = (wgid % p.tilesN) * BN;
+  // ---- this workgroup's tiles.  Blocks b and b+8 share an XCD (and its L2): XCD group x = b & 7 takes a
+  // contiguous run of row-major tiles and its workgroups walk that run side by side, so at any time the 32 tiles
+  // in flight on an XCD share a few A row panels and W column panels.
+  const int T = p.tilesM * p.tilesN;
+  int run0, ntl, wpx;
+  {
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int x = bid & 7, l = bid >> 3;
+    const int q = T >> 3, r = T & 7;
+    const int rlen = q + (x < r ? 1 : 0);
+    wpx = (nwg - x + 7) >> 3;                       // workgroups of this XCD group
+    run0 = x * q + (x < r ? x : r) + l;             // first tile of this workgroup
+    ntl = l < rlen ? (rlen - l + wpx - 1) / wpx : 0;
+  }
+  if (ntl == 0) return;
+  const int nk = p.K / BK;
 
-  // ---- DMA set-up: this wave moves rows 32w..32w+31 of the A part and of the W part of every K-tile, as 4 + 4
-  // pieces of 8 rows x 128 B; lane -> row lane>>3, physical chunk lane&7, logical chunk = physical ^ (row & 7)
+  // ---- DMA: this wave moves rows 32w..32w+31 of every A tile and of every W tile, as 4 + 4 pieces of 8 rows x
+  // 128 B; lane -> row lane>>3, physical chunk lane&7, logical chunk = physical ^ (row & 7)
   const int lr = lane >> 3;
   const int lc = (lane & 7) ^ lr;
   const bf16_t* asrc[4];
   const bf16_t* wsrc[4];
+  auto set_a = [&](int it) {
+    const int w = run0 + it * wpx;
+    const int am0 = (w / p.tilesN) * BM;
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int row = (4 * wave + q) * 8 + lr;
-    int am = m0 + row;
-    am = am < p.M ? am : p.M - 1;
-    asrc[q] = p.A + (int64_t)am * p.lda + lc * 8;
-    int wn = n0 + row;
-    wn = wn < p.N ? wn : p.N - 1;
-    wsrc[q] = p.W + (int64_t)wn * p.ldw + lc * 8;
-  }
-  auto issueA = [&](int t) {
-    char* sb = smem + (t % NA) * PART + 4 * wave * 1024;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) glds16(asrc[q] + t * BK, sb + q * 1024);
+    for (int q = 0; q < 4; ++q) {
+      int am = am0 + (4 * wave + q) * 8 + lr;
+      am = am < p.M ? am : p.M - 1;
+      asrc[q] = p.A + (int64_t)am * p.lda + lc * 8;
+    }
   };
-  auto issueW = [&](int t) {
-    char* sb = smem + WBASE + (t & 1) * PART + 4 * wave * 1024;
+  auto set_w = [&](int it) {
+    const int w = run0 + it * wpx;
+    const int wn0 = (w % p.tilesN) * BN;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) glds16(wsrc[q] + t * BK, sb + q * 1024);
+    for (int q = 0; q < 4; ++q) {
+      int wn = wn0 + (4 * wave + q) * 8 + lr;
+      wn = wn < p.N ? wn : p.N - 1;
+      wsrc[q] = p.W + (int64_t)wn * p.ldw + lc * 8;
+    }
+  };
+  set_a(0);
+  set_w(0);
+  int a_it = 0, a_t = 0, a_slot = 0;   // next A K-tile to issue: tile a_it of this workgroup, K-tile a_t, ring slot
+  int w_it = 0, w_t = 0, w_slot = 0;
+  auto issueA = [&]() -> bool {
+    if (a_it >= ntl) return false;
+    char* sb = smem + a_slot * PART + 4 * wave * 1024;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) glds16(asrc[q] + a_t * BK, sb + q * 1024);
+    a_slot = a_slot == NA - 1 ? 0 : a_slot + 1;
+    if (++a_t == nk) {
+      a_t = 0;
+      if (++a_it < ntl) set_a(a_it);
+    }
+    return true;
+  };
+  auto issueW = [&]() {
+    if (w_it >= ntl) return;
+    char* sb = smem + WBASE + w_slot * PART + 4 * wave * 1024;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) glds16(wsrc[q] + w_t * BK, sb + q * 1024);
+    w_slot ^= 1;
+    if (++w_t == nk) {
+      w_t = 0;
+      if (++w_it < ntl) set_w(w_it);
+    }
   };
 
-  // ---- fragment addressing (slot-relative): lane reads row (lane&15) of a 16-row tile, logical chunk 4kk + lane>>4
+  // ---- fragment addressing (tile-relative): lane reads row (lane&15) of a 16-row block, logical chunk 4kk + lane>>4
   int offA[2], offB[2];
 #pragma unroll
   for (int kk = 0; kk < 2; ++kk) {
@@ -109,18 +201,13 @@ __global__ __launch_bounds__(NT, 2) void gemm_pp_kernel(const GemmArgs p) {
     offA[kk] = (grp * 128 + (lane & 15)) * 128 + pch;
     offB[kk] = WBASE + (wc * 64 + (lane & 15)) * 128 + pch;
   }
+  int ca = 0, cw = 0;  // ring slots of the K-tile being consumed
 
   f32x4_t acc[8][4];
-#pragma unroll
-  for (int i = 0; i < 8; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-
   bf16x8_t a[8], b[4];
-  auto load_frags = [&](int t, int kk) {
-    if ((PP_ABLATE & 2) && (t | kk)) return;
-    const char* sa = smem + (t % NA) * PART;
-    const char* sw = smem + (t & 1) * PART;
+  auto load_frags = [&](int kk) {
+    const char* sa = smem + ca * PART;
+    const char* sw = smem + cw * PART;
 #pragma unroll
     for (int j = 0; j < 4; ++j) b[j] = *(const bf16x8_t*)(sw + offB[kk] + j * 2048);
 #pragma unroll
@@ -139,193 +226,184 @@ __global__ __launch_bounds__(NT, 2) void gemm_pp_kernel(const GemmArgs p) {
     __builtin_amdgcn_sched_barrier(0);
   };
 
-  const int nk = p.K / BK;
+  // ---- prologue of the K-tile stream: A(0) W(0) A(1) in flight, K-tile 0 landed and published
+  issueA();
+  issueW();
+  wait_dma(issueA());
+  seg_barrier();
   const bool dma = (PP_ABLATE & 1) == 0;
 
-  STAMP(0);
-  // ---- prologue.  Issue order is what makes the counted waits work (vmcnt retires in order): A(0) W(0) A(1),
-  // then per K-tile t: W(t+1) in the wave's L(t,0), A(t+2) in its L(t,1); "vmcnt(4)" at the end of segment 3 leaves the 4
-  // pieces of A(t+2) in flight and guarantees A(t+1), W(t+1) and everything older have landed.
-  issueA(0);
-  issueW(0);
-  if (nk > 1) {
-    issueA(1);
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-  } else {
-    wait_dma_all();
-  }
-  seg_barrier();
-  STAMP(1);
+  for (int it = 0; it < ntl; ++it) {
+    const int wgid = run0 + it * wpx;
+    const int m0 = (wgid / p.tilesN) * BM;
+    const int n0 = (wgid % p.tilesN) * BN;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
-  // DMA is issued only from LOAD segments: a piece blocks its wave for 60-180 cycles while the address unit takes
-  // it, which inside a COMPUTE segment would stall the matrix pipe directly.
-  if (grp == 0) {
+    STAMP(0);
+#ifdef PP_STAMP
+    if (tid == 0 && it < 12 && p.resid) ((unsigned long long*)p.resid)[((size_t)blockIdx.x * 12 + it) * 4 + 3] = __builtin_amdgcn_s_memrealtime();
+#endif
+    if (grp == 1) seg_barrier();   // group 0's first LOAD of the tile
     for (int t = 0; t < nk; ++t) {
-      load_frags(t, 0);
-      if (dma && t + 1 < nk && !(PP_ABLATE & 8)) issueW(t + 1);    // segment 0: L(t,0)
+      // ---- L(t,0)
+      load_frags(0);
+      if (dma) issueW();           // W(g+1)
       wait_lds();
       seg_barrier();
-      compute();                                                   // segment 1: C(t,0)
+      // ---- C(t,0)
+      compute();
       seg_barrier();
-      load_frags(t, 1);
-      if (dma && t + 2 < nk && !(PP_ABLATE & 16)) issueA(t + 2);   // segment 2: L(t,1)
+      // ---- L(t,1)
+      load_frags(1);
+      const bool keep = dma ? issueA() : false;   // A(g+2)
       wait_lds();
+      if (grp == 1) wait_dma(keep);   // group 1: its L(t,1) IS segment 3
       seg_barrier();
-      compute();                                                   // segment 3: C(t,1)
-      if (t + 2 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else wait_dma_all();
+      // ---- C(t,1)
+      compute();
+      if (grp == 0) wait_dma(keep);   // group 0: its C(t,1) is segment 3
       seg_barrier();
+      ca = ca == NA - 1 ? 0 : ca + 1;
+      cw ^= 1;
     }
-    seg_barrier();                     // group 1's last COMPUTE
-  } else {
-    seg_barrier();                     // group 0's first LOAD
-    for (int t = 0; t < nk; ++t) {
-      load_frags(t, 0);
-      if (dma && t + 1 < nk && !(PP_ABLATE & 8)) issueW(t + 1);    // segment 1: L(t,0)
-      wait_lds();
-      seg_barrier();
-      compute();                                                   // segment 2: C(t,0)
-      seg_barrier();
-      load_frags(t, 1);
-      if (dma && t + 2 < nk && !(PP_ABLATE & 16)) issueA(t + 2);   // segment 3: L(t,1)
-      wait_lds();
-      if (t + 2 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else wait_dma_all();
-      seg_barrier();
-      compute();                                                   // segment 0 of K-tile t+1: C(t,1)
-      seg_barrier();
-    }
-  }
+    if (grp == 0) seg_barrier();   // group 1's last COMPUTE of the tile
+    STAMP(1);
 
-  STAMP(2);
-  // ---- epilogue.  The MFMAs ran with the weight tile as the A operand, so a lane holds, for each (i, j),
-  // 4 CONSECUTIVE output columns of one output row:
-  //   acc[i][j][r] = out[m0 + 128 grp + 16 i + (lane & 15)][n0 + 64 wc + 16 j + 4 (lane >> 4) + r]
-  const int mrow = grp * 128 + (lane & 15);        // + 16 i
-  const int ncol = wc * 64 + 4 * (lane >> 4);      // + 16 j
-  if (EPI != VITM_EPI_RESIDUAL && !OUT_F32) {
-    // Fast path: bias / LayerNorm fix-up / GELU on the accumulators in place (fp32), one rounding to bf16,
-    // then the whole 256x256 bf16 tile crosses LDS once (8-byte writes, 16-byte reads) so that global stores
-    // are full 512-byte row segments.  Stores are left in flight: nothing waits for them.
-    float4 cq[4], sq[4];
+    // ---- epilogue (registers only).  acc[i][j][r] = out[m0 + 128 grp + 16 i + (lane & 15)][n0 + 64 wc + 16 j + 4 q + r],
+    // q = lane >> 4.  After the permlane16 swap of tiles (j, j+1), j even, a lane with q even holds columns
+    // 16 j + 4 q .. +7 and a lane with q odd holds columns 16 (j+1) + 4 (q-1) .. +7.
+    const int q4 = lane >> 4;
+    const bool hi8 = (lane & 8) != 0;
+    const int mrow = m0 + grp * 128 + (lane & 15);            // + 16 i  (accumulator layout)
+    const int mst = m0 + grp * 128 + (lane & 7);              // + 16 i (+ 8 for the second store)
+    const int ncol = n0 + wc * 64 + 4 * q4;                   // + 16 j   (accumulator layout)
+    const int nsw = n0 + wc * 64 + ((q4 & 1) ? 16 + 4 * (q4 - 1) : 4 * q4);   // + 32 jp: columns held after the swap
+    const int nst = nsw + (hi8 ? 32 : 0);                                       // columns stored after the row-pair exchange
+    float4 cq[4], sq[4], gq[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      int n = n0 + ncol + 16 * j;
-      n = n < p.N ? n : p.N - 4;   // N % 8 == 0: a clamped quad is read but never stored
+      int n = ncol + 16 * j;
+      n = n < p.N ? n : p.N - 4;   // N % 8 == 0: a clamped quad is computed but never stored
       cq[j] = *(const float4*)(p.c + n);
       if (EPI == VITM_EPI_LN || EPI == VITM_EPI_LN_GELU) sq[j] = *(const float4*)(p.s + n);
+      if (EPI == VITM_EPI_RESIDUAL) gq[j] = *(const float4*)(p.g + n);
     }
-    constexpr int TS = 528;  // bytes per LDS row of the bf16 tile image (512 + 16)
+    float2 st[8];
+    if (EPI == VITM_EPI_LN || EPI == VITM_EPI_LN_GELU) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      float2 st = make_float2(0.f, 1.f);
-      if (EPI == VITM_EPI_LN || EPI == VITM_EPI_LN_GELU) {
-        int m = m0 + mrow + 16 * i;
+      for (int i = 0; i < 8; ++i) {
+        int m = mrow + 16 * i;
         m = m < p.M ? m : p.M - 1;
-        st = *(const float2*)(p.stats + 2 * (int64_t)m);
+        st[i] = *(const float2*)(p.stats + 2 * (int64_t)m);
       }
-      f32x2_t v[8];  // the 16 values of row i: pairs (j, half)
+    }
+    const bool stores_on = (PP_ABLATE & 4) == 0;
+    if (EPI != VITM_EPI_RESIDUAL) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const f32x2_t c01 = {cq[j].x, cq[j].y}, c23 = {cq[j].z, cq[j].w};
-        v[2 * j] = (f32x2_t){acc[i][j][0], acc[i][j][1]};
-        v[2 * j + 1] = (f32x2_t){acc[i][j][2], acc[i][j][3]};
-        if (EPI == VITM_EPI_LN || EPI == VITM_EPI_LN_GELU) {
-          const f32x2_t s01 = {sq[j].x, sq[j].y}, s23 = {sq[j].z, sq[j].w};
-          v[2 * j] = (v[2 * j] - s01 * st.x) * st.y + c01;       // rstd * (acc - mean * s) + c
-          v[2 * j + 1] = (v[2 * j + 1] - s23 * st.x) * st.y + c23;
-        } else {
-          v[2 * j] += c01;
-          v[2 * j + 1] += c23;
+      for (int i = 0; i < 8; ++i) {
+        f32x2_t v[8];  // the 16 values of row i: pairs (j, half)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const f32x2_t c01 = {cq[j].x, cq[j].y}, c23 = {cq[j].z, cq[j].w};
+          v[2 * j] = (f32x2_t){acc[i][j][0], acc[i][j][1]};
+          v[2 * j + 1] = (f32x2_t){acc[i][j][2], acc[i][j][3]};
+          if (EPI == VITM_EPI_LN || EPI == VITM_EPI_LN_GELU) {
+            const f32x2_t s01 = {sq[j].x, sq[j].y}, s23 = {sq[j].z, sq[j].w};
+            v[2 * j] = (v[2 * j] - s01 * st[i].x) * st[i].y + c01;       // rstd * (acc - mean * s) + c
+            v[2 * j + 1] = (v[2 * j + 1] - s23 * st[i].x) * st[i].y + c23;
+          } else {
+            v[2 * j] += c01;
+            v[2 * j + 1] += c23;
+          }
+        }
+        if (EPI == VITM_EPI_LN_GELU || EPI == VITM_EPI_BIAS_GELU) gelu_erf2_n<8>(v);
+        // chunk jp = this lane's row, columns nsw + 32 jp .. +7, as dwords (a, b, c, d)
+        unsigned a0 = pack_bf2(v[0].x, v[0].y), b0 = pack_bf2(v[1].x, v[1].y);
+        unsigned c0 = pack_bf2(v[2].x, v[2].y), d0 = pack_bf2(v[3].x, v[3].y);
+        unsigned a1 = pack_bf2(v[4].x, v[4].y), b1 = pack_bf2(v[5].x, v[5].y);
+        unsigned c1 = pack_bf2(v[6].x, v[6].y), d1 = pack_bf2(v[7].x, v[7].y);
+        swap16(a0, c0);   // (tile 0 quad lo, tile 1 quad lo) -> 8 consecutive columns: a b | c d
+        swap16(b0, d0);
+        swap16(a1, c1);
+        swap16(b1, d1);
+        rowpair_exchange1(a0, a1, hi8);
+        rowpair_exchange1(b0, b1, hi8);
+        rowpair_exchange1(c0, c1, hi8);
+        rowpair_exchange1(d0, d1, hi8);
+        if (stores_on && nst < p.N) {
+          const int m1 = mst + 16 * i, m2 = m1 + 8;
+          bf16_t* o = (bf16_t*)p.out + (int64_t)m1 * p.ldo + nst;
+          if (m1 < p.M) store_out(o, a0, b0, c0, d0);
+          if (m2 < p.M) store_out(o + 8 * p.ldo, a1, b1, c1, d1);
         }
       }
-      if (EPI == VITM_EPI_LN_GELU || EPI == VITM_EPI_BIAS_GELU) gelu_erf2_n<8>(v);
+    } else {
+      // residual: out = resid + (g * acc + c), one rounding.  The fp32 values are swapped (4 dwords per quad) so
+      // the residual is read and the result written as 16 bytes per lane.  Two halves of 4 rows keep the
+      // residual values of a half in registers before its first store.
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        uint2 w;
-        w.x = pack_bf2(v[2 * j].x, v[2 * j].y);
-        w.y = pack_bf2(v[2 * j + 1].x, v[2 * j + 1].y);
-        *(uint2*)(smem + (mrow + 16 * i) * TS + (ncol + 16 * j) * 2) = w;
-      }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    seg_barrier();
-    STAMP(3);
-    const int ch = tid & 31, rp = tid >> 5;   // 16-byte chunk of the row, row within a 16-row pass
-    const int n = n0 + ch * 8;
-    if (n < p.N && (PP_ABLATE & 4) == 0) {
-      bf16_t* obase = (bf16_t*)p.out + n;
+      for (int ih = 0; ih < 2; ++ih) {
+        uint4 rres[4][2];   // residual in store layout: [.][0] row (r&7), [.][1] row 8 + (r&7), columns nst .. +7
 #pragma unroll
-      for (int pass = 0; pass < 16; ++pass) {
-        const int row = pass * 16 + rp;
-        const int m = m0 + row;
-        if (m < p.M) {
-          const uint4 w = *(const uint4*)(smem + row * TS + ch * 16);
-          *(uint4*)(obase + (int64_t)m * p.ldo) = w;
+        for (int i4 = 0; i4 < 4; ++i4)
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            int m = mst + 16 * (4 * ih + i4) + 8 * h;
+            m = m < p.M ? m : p.M - 1;
+            const int n = nst < p.N ? nst : p.N - 8;
+            rres[i4][h] = *(const uint4*)(p.resid + (int64_t)m * p.ldr + n);
+          }
+#pragma unroll
+        for (int i4 = 0; i4 < 4; ++i4) {
+          const int i = 4 * ih + i4;
+          unsigned lo0[4], hi0[4], lo1[4], hi1[4];   // fp32 bits of chunk 0 / chunk 1: columns +0..3 (lo) and +4..7 (hi)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float g0[4] = {gq[0].x, gq[0].y, gq[0].z, gq[0].w}, cc0[4] = {cq[0].x, cq[0].y, cq[0].z, cq[0].w};
+            const float g1[4] = {gq[1].x, gq[1].y, gq[1].z, gq[1].w}, cc1[4] = {cq[1].x, cq[1].y, cq[1].z, cq[1].w};
+            const float g2[4] = {gq[2].x, gq[2].y, gq[2].z, gq[2].w}, cc2[4] = {cq[2].x, cq[2].y, cq[2].z, cq[2].w};
+            const float g3[4] = {gq[3].x, gq[3].y, gq[3].z, gq[3].w}, cc3[4] = {cq[3].x, cq[3].y, cq[3].z, cq[3].w};
+            float l0 = fmaf(g0[e], acc[i][0][e], cc0[e]), h0 = fmaf(g1[e], acc[i][1][e], cc1[e]);
+            float l1 = fmaf(g2[e], acc[i][2][e], cc2[e]), h1 = fmaf(g3[e], acc[i][3][e], cc3[e]);
+            swap16(l0, h0);
+            swap16(l1, h1);
+            lo0[e] = __builtin_bit_cast(unsigned, l0);
+            hi0[e] = __builtin_bit_cast(unsigned, h0);
+            lo1[e] = __builtin_bit_cast(unsigned, l1);
+            hi1[e] = __builtin_bit_cast(unsigned, h1);
+            rowpair_exchange1(lo0[e], lo1[e], hi8);
+            rowpair_exchange1(hi0[e], hi1[e], hi8);
+          }
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const uint4 rv = rres[i4][h];
+            const unsigned* l4 = h ? lo1 : lo0;
+            const unsigned* h4 = h ? hi1 : hi0;
+            uint4 o;
+            o.x = pack_bf2(__builtin_bit_cast(float, rv.x << 16) + __builtin_bit_cast(float, l4[0]),
+                           __builtin_bit_cast(float, rv.x & 0xffff0000u) + __builtin_bit_cast(float, l4[1]));
+            o.y = pack_bf2(__builtin_bit_cast(float, rv.y << 16) + __builtin_bit_cast(float, l4[2]),
+                           __builtin_bit_cast(float, rv.y & 0xffff0000u) + __builtin_bit_cast(float, l4[3]));
+            o.z = pack_bf2(__builtin_bit_cast(float, rv.z << 16) + __builtin_bit_cast(float, h4[0]),
+                           __builtin_bit_cast(float, rv.z & 0xffff0000u) + __builtin_bit_cast(float, h4[1]));
+            o.w = pack_bf2(__builtin_bit_cast(float, rv.w << 16) + __builtin_bit_cast(float, h4[2]),
+                           __builtin_bit_cast(float, rv.w & 0xffff0000u) + __builtin_bit_cast(float, h4[3]));
+            const int m = mst + 16 * i + 8 * h;
+            if (stores_on && m < p.M && nst < p.N) store_out((bf16_t*)p.out + (int64_t)m * p.ldo + nst, o.x, o.y, o.z, o.w);
+          }
         }
       }
     }
-    STAMP(4);
-#ifdef PP_STAMP
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    STAMP(5);
-#endif
-    return;
-  }
-
-  // Staged path (residual add, or fp32 output): 128 rows at a time through LDS in fp32 (16-byte writes), then
-  // the row-contiguous fix-up reads the residual with 16-byte loads and rounds once.
-  float* Cs = (float*)smem;
-  const int cch = tid & 31, rp = tid >> 5;  // thread -> 8 columns cch*8.., row rp of each 16-row pass
-  const int n = n0 + cch * 8;
-  EpiCols<EPI> cols;
-  if (n < p.N) cols.load(p, n);
-  // every load the fix-up needs is issued before the first store, so no wait ever covers a store
-  u16x8_t rres[16];
-  float2 rst[16];
-#pragma unroll
-  for (int q = 0; q < 16; ++q) {
-    int m = m0 + q * 16 + rp;
-    m = m < p.M ? m : p.M - 1;
-    rres[q] = (u16x8_t){0, 0, 0, 0, 0, 0, 0, 0};
-    rst[q] = make_float2(0.f, 1.f);
-    if (n < p.N) {
-      if (EPI == VITM_EPI_RESIDUAL) rres[q] = *(const u16x8_t*)(p.resid + (int64_t)m * p.ldr + n);
-      if (EPI == VITM_EPI_LN || EPI == VITM_EPI_LN_GELU) rst[q] = *(const float2*)(p.stats + 2 * (int64_t)m);
-    }
-  }
-#pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    if (grp == h) {
-#pragma unroll
-      for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          *(f32x4_t*)(Cs + ((lane & 15) + 16 * i) * CS + ncol + 16 * j) = acc[i][j];
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    seg_barrier();
-    if (n < p.N && (PP_ABLATE & 4) == 0) {
-#pragma unroll
-      for (int pass = 0; pass < 8; ++pass) {
-        const int row = pass * 16 + rp;
-        const int m = m0 + h * 128 + row;
-        if (m < p.M) {
-          float v[8];
-          const float4 a0 = *(const float4*)(Cs + row * CS + cch * 8);
-          const float4 a1 = *(const float4*)(Cs + row * CS + cch * 8 + 4);
-          v[0] = a0.x; v[1] = a0.y; v[2] = a0.z; v[3] = a0.w;
-          v[4] = a1.x; v[5] = a1.y; v[6] = a1.z; v[7] = a1.w;
-          cols.template finish_pre<OUT_F32>(p, m, n, v, rres[h * 8 + pass], rst[h * 8 + pass]);
-        }
-      }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    seg_barrier();
+    STAMP(2);
   }
 }
 
-template <int EPI, int OUT_F32>
+template <int EPI>
 int launch(const GemmArgs& a, hipStream_t st) {
-  auto kfn = gemm_pp_kernel<EPI, OUT_F32>;
+  auto kfn = gemm_pp_kernel<EPI>;
   if (hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess) {
     vitm_set_error("vitm_gemm: cannot reserve %d bytes of LDS", SMEM);
     (void)hipGetLastError();
@@ -333,8 +411,12 @@ int launch(const GemmArgs& a, hipStream_t st) {
   }
   GemmArgs b = a;
   b.tilesN = (a.N + BN - 1) / BN;
-  const int tilesM = (a.M + BM - 1) / BM;
-  hipLaunchKernelGGL(kfn, dim3((unsigned)(tilesM * b.tilesN)), dim3(NT), SMEM, st, b);
+  b.tilesM = (a.M + BM - 1) / BM;
+  int dev = 0, ncu = 256;
+  if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+  const int64_t tiles = (int64_t)b.tilesM * b.tilesN;
+  const int grid = (int)(tiles < ncu ? tiles : ncu);   // one persistent workgroup per CU
+  hipLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3(NT), SMEM, st, b);
   VITM_CHECK_LAUNCH("vitm_gemm (256x256 tile)");
   return VITM_OK;
 }
@@ -347,22 +429,13 @@ bool vitm_gemm_pp_wanted(int M, int N, int K) {
   return K % BK == 0 && M >= 1024 && N >= 256 && tiles >= 128;
 }
 
-int vitm_gemm_pp_launch(const GemmArgs& a, int epilogue, int out_f32, hipStream_t st) {
-  if (out_f32) {
-    switch (epilogue) {
-      case VITM_EPI_BIAS: return launch<VITM_EPI_BIAS, 1>(a, st);
-      case VITM_EPI_LN: return launch<VITM_EPI_LN, 1>(a, st);
-      default: break;
-    }
-    vitm_set_error("vitm_gemm: fp32 output supports only the BIAS and LN epilogues");
-    return VITM_EUNSUPPORTED;
-  }
+int vitm_gemm_pp_launch(const GemmArgs& a, int epilogue, hipStream_t st) {
   switch (epilogue) {
-    case VITM_EPI_BIAS: return launch<VITM_EPI_BIAS, 0>(a, st);
-    case VITM_EPI_BIAS_GELU: return launch<VITM_EPI_BIAS_GELU, 0>(a, st);
-    case VITM_EPI_LN: return launch<VITM_EPI_LN, 0>(a, st);
-    case VITM_EPI_LN_GELU: return launch<VITM_EPI_LN_GELU, 0>(a, st);
-    case VITM_EPI_RESIDUAL: return launch<VITM_EPI_RESIDUAL, 0>(a, st);
+    case VITM_EPI_BIAS: return launch<VITM_EPI_BIAS>(a, st);
+    case VITM_EPI_BIAS_GELU: return launch<VITM_EPI_BIAS_GELU>(a, st);
+    case VITM_EPI_LN: return launch<VITM_EPI_LN>(a, st);
+    case VITM_EPI_LN_GELU: return launch<VITM_EPI_LN_GELU>(a, st);
+    case VITM_EPI_RESIDUAL: return launch<VITM_EPI_RESIDUAL>(a, st);
     default: break;
   }
   vitm_set_error("vitm_gemm: unknown epilogue %d", epilogue);
