@@ -1,0 +1,16 @@
+#!/bin/bash
+# Profile collection for one round (run on the GPU box from the repo root):  bash profiles/collect.sh r1
+# Pass 1: kernel trace + stats of the bench command.  Passes 2-4: PMC counters, each in a run of its own with
+# kernel-trace only (TCC FETCH_SIZE and WRITE_SIZE do not fit one pass; SQ counters a third).
+set -e
+R=${1:-r1}
+OUT=gpurun_out/prof_$R
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+BENCH="python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline"
+timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH > $OUT/bench_trace.log 2>&1
+SHORT="python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline"
+timeout -s KILL 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $SHORT > $OUT/pmc_fetch.log 2>&1
+timeout -s KILL 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- $SHORT > $OUT/pmc_write.log 2>&1
+timeout -s KILL 200 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_LDS_BANK_CONFLICT SQ_WAIT_ANY GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_sq -- $SHORT > $OUT/pmc_sq.log 2>&1
+find $OUT -name "*.csv" | head -20

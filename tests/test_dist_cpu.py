@@ -1,0 +1,65 @@
+"""world_size-2 gloo rehearsal of the multi-GPU path on the CPU: each rank takes its contiguous batch shard and runs
+the forward on it with no data-path collective; the concatenation of the shards' outputs equals the unsharded
+forward bit for bit, and the slowest rank's time is what every rank reports.  (The CPU oracle stands in for the
+per-rank compute here; on the GPU box the same invariant is checked on the HIP path in
+test_gpu_model.py::test_batch_independence_and_determinism.)"""
+import os
+import socket
+import sys
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, q):
+    for p in (ROOT, os.path.join(ROOT, "vision-transformer_amd"), os.path.join(ROOT, "tests", "golden")):
+        sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import weights as W
+        from oracle import vit_oracle as O
+        from vitm_amd.sharding import shard_bounds, max_over_ranks
+        cfg = W.CONFIGS["tiny2"]
+        sd = {k: torch.from_numpy(v) for k, v in W.make_state_dict(cfg, 0).items()}
+        x = torch.from_numpy(W.make_input(cfg, 5, 77))      # 5 images over 2 ranks: shards of 3 and 2
+        s, e = shard_bounds(x.shape[0], world, rank)
+        mine = O.vitc_forward(x[s:e], sd, W.oracle_cfg(cfg))
+        # outputs stay per rank; gathering them is NOT part of the data path -- done here only to check
+        parts = [None] * world
+        dist.all_gather_object(parts, (s, e, mine))
+        slow = max_over_ranks(1.0 + rank, dist)             # rank r "took" 1 + r seconds
+        if rank == 0:
+            full = O.vitc_forward(x, sd, W.oracle_cfg(cfg))
+            got = torch.cat([p[2] for p in sorted(parts, key=lambda t: t[0])])
+            q.put((bool(torch.equal(got, full)), [(p[0], p[1]) for p in parts], slow))
+        else:
+            assert slow == float(world)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_batch_sharding_equals_unsharded_forward():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    same, bounds, slow = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert same, "sharded forward differs from the unsharded one"
+    assert sorted(bounds) == [(0, 3), (3, 5)]
+    assert slow == 2.0
