@@ -9,8 +9,10 @@
  * Conventions
  *  - every pointer is a DEVICE pointer owned by the caller; the library never allocates or frees;
  *  - matrices are row-major with an explicit leading dimension in ELEMENTS;
- *  - activations are bf16 unless an `*_dtype` argument says otherwise; small per-channel vectors
- *    (biases, LayerNorm affine, LayerScale, folded-LN sums) are fp32;
+ *  - activations are bf16 unless an `*_dtype` argument says otherwise or the entry point is one of
+ *    the `*_f32` family (the full-precision path: fp32 operands, fp32 matrix instructions, erf-accurate
+ *    GELU; it serves fp32 callers, who expect 1e-4 agreement with an fp32 reference);
+ *  - small per-channel vectors (biases, LayerNorm affine, LayerScale, folded-LN sums) are fp32;
  *  - calls are asynchronous on `stream` (a hipStream_t; NULL = the default stream) and run on
  *    the calling thread's current HIP device; the library keeps no mutable global state;
  *  - return 0 on success, a negative VITM_E* code otherwise; vitm_last_error() returns a
@@ -54,18 +56,19 @@ int vitm_gemm_k_multiple(void);
 /*
  * One-time weight packing for a Linear / patch-projection layer, optionally folding the LayerNorm
  * that precedes it and the LayerScale that follows it:
- *   wp[n,k] = bf16(w[n,k] * ln_gamma[k])           k < K, zero for K <= k < kpad
+ *   wp[n,k] = wp_dtype(w[n,k] * ln_gamma[k])       k < K, zero for K <= k < kpad
  *   s[n]    = sum_k float(wp[n,k])                 (only when s != NULL)
  *   c[n]    = (sum_k ln_beta[k] * w[n,k] + bias[n]) * out_scale[n]
  *   g[n]    = out_scale[n]                         (only when g != NULL)
  * Null ln_gamma / ln_beta / bias / out_scale mean 1 / 0 / 0 / 1.  `w` is [N,K] row-major in
- * `w_dtype` (nn.Linear.weight, or Conv2d.weight viewed as (D, C*ph*pw)); vectors are fp32.
+ * `w_dtype` (nn.Linear.weight, or Conv2d.weight viewed as (D, C*ph*pw)); `wp` is [N,kpad] in
+ * `wp_dtype` (bf16 for vitm_gemm, fp32 for vitm_gemm_f32); vectors are fp32.
  * Replaces nothing at run time: it prepares nn.Linear weights (models.py:51,57,121,124),
  * nn.LayerNorm affines (models.py:189,196) and LayerScale.gamma (models.py:135) for the fused GEMMs.
  */
 int vitm_prepack_linear(const void* w, int w_dtype, const float* bias, const float* ln_gamma,
                         const float* ln_beta, const float* out_scale, int N, int K, int kpad,
-                        void* wp, float* s, float* c, float* g, vitm_stream_t stream);
+                        void* wp, int wp_dtype, float* s, float* c, float* g, vitm_stream_t stream);
 
 /*
  * Row statistics of LayerNorm: stats[m] = (mean, 1/sqrt(var + eps)) over x[m, 0:D], x bf16 or f32.
@@ -104,12 +107,28 @@ int vitm_patch_embed(const void* img, int img_dtype, int B, int C, int H, int W,
                      int64_t ldo, int D, int cls_slot, vitm_stream_t stream);
 
 /*
- * In place on x (B, 1+Np, D) bf16: row 0 <- class token; token rows optionally LayerNorm'ed with
+ * Full-precision GEMM: as vitm_gemm with A, Wp, out and resid all fp32 and the fp32 matrix
+ * instruction.  K a multiple of vitm_gemm_k_multiple(), N and the leading dimensions multiples of 4.
+ * Epilogues: VITM_EPI_BIAS, VITM_EPI_BIAS_GELU (erf to 1.5e-7), VITM_EPI_RESIDUAL; LayerNorm is not
+ * folded on this path (call vitm_layernorm first).  Replaces the same reference lines as vitm_gemm
+ * for fp32 tensors.
+ */
+int vitm_gemm_f32(const float* A, int64_t lda, const float* Wp, int64_t ldw, float* out, int64_t ldo,
+                  int M, int N, int K, int epilogue, const float* c, const float* g,
+                  const float* resid, int64_t ldr, int row_group, vitm_stream_t stream);
+
+/* vitm_patch_embed with an fp32 packed weight and fp32 tokens (patch_embeddings.py:115-117). */
+int vitm_patch_embed_f32(const void* img, int img_dtype, int B, int C, int H, int W, int ph, int pw,
+                         const float* Wp, int64_t ldw, int kpad, const float* c, float* tokens,
+                         int64_t ldo, int D, int cls_slot, vitm_stream_t stream);
+
+/*
+ * In place on x (B, 1+Np, D), bf16 or fp32 (x_dtype): row 0 <- class token; token rows optionally LayerNorm'ed with
  * (en_w,en_b) (PatchEmbed.norm_layer); then every row optionally LayerNorm'ed with (np_w,np_b)
  * (norm_pre), then + pos[n,:].  Null pointers skip the step.
  * Replaces patch_embeddings.py:120 and VisionTransformer.forward_features (models.py:356-360).
  */
-int vitm_embed_finalize(void* x, int64_t ldx, int B, int ntok, int D, const float* cls,
+int vitm_embed_finalize(void* x, int x_dtype, int64_t ldx, int B, int ntok, int D, const float* cls,
                         const float* pos, const float* en_w, const float* en_b, float en_eps,
                         const float* np_w, const float* np_b, float np_eps, vitm_stream_t stream);
 
@@ -124,14 +143,22 @@ int vitm_attention(const void* qkv, int64_t ldqkv, void* out, int64_t ldo, int B
                    int head_dim, float scale, vitm_stream_t stream);
 
 /*
- * Full LayerNorm: out[m,:] = (x[m,:] - mean) * rstd * w + b over D; x bf16, out bf16 or f32.
- * Replaces norm_final (models.py:410) and PatchEmbed.norm_layer when used stand-alone.
+ * Same attention with fp32 qkv and out and fp32 arithmetic throughout (leading dimensions multiples
+ * of 4).  Replaces models.py:79-93 for fp32 tensors.
  */
-int vitm_layernorm(const void* x, int64_t ldx, void* out, int out_dtype, int64_t ldo, int M, int D,
-                   const float* w, const float* b, float eps, vitm_stream_t stream);
+int vitm_attention_f32(const float* qkv, int64_t ldqkv, float* out, int64_t ldo, int B, int N, int H,
+                       int head_dim, float scale, vitm_stream_t stream);
 
-/* out[m,n] = x[m,n] * gamma[n]  (LayerScale.forward stand-alone, models.py:138-139); bf16. */
-int vitm_scale_channels(const void* x, int64_t ldx, void* out, int64_t ldo, int M, int D,
+/*
+ * Full LayerNorm: out[m,:] = (x[m,:] - mean) * rstd * w + b over D; x and out each bf16 or f32.
+ * Replaces norm_final (models.py:410), PatchEmbed.norm_layer when used stand-alone, and norm1 /
+ * norm2 (models.py:209-210) on the fp32 path.
+ */
+int vitm_layernorm(const void* x, int x_dtype, int64_t ldx, void* out, int out_dtype, int64_t ldo,
+                   int M, int D, const float* w, const float* b, float eps, vitm_stream_t stream);
+
+/* out[m,n] = x[m,n] * gamma[n]  (LayerScale.forward stand-alone, models.py:138-139); x and out in `dtype`. */
+int vitm_scale_channels(const void* x, int64_t ldx, void* out, int64_t ldo, int dtype, int M, int D,
                         const float* gamma, vitm_stream_t stream);
 
 /* dst (bf16) <- src (f32), n elements; used to bring fp32 images/activations onto the bf16 path. */

@@ -1,0 +1,206 @@
+"""The fp32 path on a real MI355X: fp32 tensors run fp32 kernels end to end (fp32 MFMA GEMM with erf-accurate
+GELU, fp32 attention, explicit LayerNorm) and must agree with an fp32 reference to 1e-4 relative -- the bar
+BASELINE.json's north star states for fp32.  "Relative" is max|got - ref| / max|ref| over the tensor.
+
+Kernels are checked against float64 PyTorch statements of the same op; the model against the golden fixtures
+captured from the imported reference's fp32 CPU forward, and (CIFAR ViT-tiny, batch 64: the reference's own
+CPU-runnable configuration) against the CPU oracle.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+import weights as W
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+REL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from vitm_amd import _ops
+    return _ops
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(DEV)
+
+
+def _rel(got, ref):
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    assert torch.isfinite(got).all()
+    return ((got.double() - ref.double()).abs().max() / ref.double().abs().max().clamp_min(1e-30)).item()
+
+
+@pytest.mark.parametrize("epi", ["bias", "gelu", "resid"])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 136, 128), (1, 8, 64), (197 * 3, 768, 768), (333, 616, 192),
+                                   (1000, 768, 3072)])
+def test_gemm_f32(ops, M, N, K, epi):
+    A = _rand(M, K, seed=1)
+    Wt, b = _rand(N, K, seed=2, scale=K ** -0.5), _rand(N, seed=3, scale=0.3)
+    lin = A.double() @ Wt.double().t() + b.double()
+    if epi == "resid":
+        gamma = 1.0 + 0.1 * _rand(N, seed=4)
+        x = _rand(M, N, seed=5)
+        ref = x.double() + gamma.double() * lin
+        pk = ops.pack_linear(Wt, b, out_scale=gamma, dtype=torch.float32)
+        ops.gemm(A, pk, x, ops.EPI_RESIDUAL, M, resid=x)
+        assert _rel(x, ref) <= REL
+        return
+    pk = ops.pack_linear(Wt, b, dtype=torch.float32)
+    assert pk.wp.dtype == torch.float32 and pk.kpad == K
+    out = torch.full((M, pk.npad), float("nan"), dtype=torch.float32, device=DEV)
+    ops.gemm(A, pk, out, ops.EPI_BIAS_GELU if epi == "gelu" else ops.EPI_BIAS, M)
+    ref = torch.nn.functional.gelu(lin) if epi == "gelu" else lin
+    assert _rel(out[:, :N], ref) <= REL
+
+
+def test_gemm_f32_identity_is_exact(ops):
+    K = N = 128
+    A = torch.eye(K, device=DEV)
+    Wt = torch.arange(N, device=DEV).float()[:, None] * 0.5 + torch.arange(K, device=DEV).float()[None, :] * 0.0078125
+    pk = ops.pack_linear(Wt, None, dtype=torch.float32)
+    out = torch.empty((K, N), dtype=torch.float32, device=DEV)
+    ops.gemm(A, pk, out, ops.EPI_BIAS, K)
+    assert torch.equal(out, Wt.t())
+
+
+def test_gemm_f32_refuses_folded_layernorm(ops):
+    from vitm_amd import VitmError
+    pk = ops.pack_linear(_rand(8, 64), None, dtype=torch.float32)
+    with pytest.raises(VitmError):
+        ops.gemm(_rand(8, 64), pk, torch.empty((8, 8), device=DEV), ops.EPI_LN, 8)
+
+
+def _attn_ref(qkv, B, N, H, hd):
+    D = H * hd
+    q, k, v = qkv.double().reshape(B, N, 3, H, hd).permute(2, 0, 3, 1, 4)
+    s = (q * hd ** -0.5) @ k.transpose(-2, -1)
+    return (s.softmax(-1) @ v).transpose(1, 2).reshape(B * N, D)
+
+
+@pytest.mark.parametrize("B,N,H,hd", [(2, 197, 3, 64), (1, 65, 2, 64), (1, 577, 2, 64), (2, 1, 2, 64), (1, 65, 2, 96),
+                                      (1, 197, 2, 32), (1, 100, 1, 128), (1, 300, 1, 64)])
+def test_attention_f32(ops, B, N, H, hd):
+    D = H * hd
+    qkv = _rand(B * N, 3 * D, seed=20) * 1.5
+    out = torch.full((B * N, D), float("nan"), dtype=torch.float32, device=DEV)
+    ops.attention(qkv, out, B, N, H, hd, hd ** -0.5)
+    assert _rel(out, _attn_ref(qkv, B, N, H, hd)) <= REL
+
+
+def test_attention_f32_online_softmax_rescale(ops):
+    B, N, H, hd = 1, 197, 1, 64
+    qkv = _rand(B * N, 3 * hd, seed=21)
+    for key_row in (5, 100, 196):
+        t = qkv.clone()
+        t[key_row, hd:2 * hd] = qkv[7, :hd] * 6.0
+        out = torch.empty((N, hd), dtype=torch.float32, device=DEV)
+        ops.attention(t, out, B, N, H, hd, hd ** -0.5)
+        assert _rel(out, _attn_ref(t, B, N, H, hd)) <= REL
+
+
+@pytest.mark.parametrize("img_dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("img,p,D,B", [(224, 16, 768, 2), (32, 4, 192, 3), (28, 14, 64, 1), (30, 6, 64, 2)])
+def test_patch_embed_f32(ops, img, p, D, B, img_dtype):
+    from oracle import vit_oracle as O
+    x = _rand(B, 3, img, img, seed=22).to(img_dtype)
+    w, b = _rand(D, 3, p, p, seed=23, scale=(3 * p * p) ** -0.5), _rand(D, seed=24, scale=0.1)
+    pk = ops.pack_linear(w, b, dtype=torch.float32)
+    Np = (img // p) ** 2
+    for cls_slot in (False, True):
+        tok = torch.full((B * (Np + int(cls_slot)), D), 7.0, dtype=torch.float32, device=DEV)
+        ops.patch_embed(x, pk, tok, (p, p), D, cls_slot)
+        cols = O.im2col(x.float().cpu(), (p, p)).to(DEV).double()
+        ref = cols @ w.double().reshape(D, -1).t() + b.double()
+        got = tok.view(B, Np + int(cls_slot), D)
+        if cls_slot:
+            assert (got[:, 0] == 7.0).all()
+            got = got[:, 1:]
+        assert _rel(got, ref) <= REL
+
+
+def test_row_kernels_f32(ops):
+    B, N, D = 3, 65, 192
+    F = torch.nn.functional
+    tok = _rand(B * N, D, seed=25) * 2 + 0.5
+    cls, pos = _rand(D, seed=26), _rand(N, D, seed=27)
+    ew, eb = 1 + 0.1 * _rand(D, seed=28), 0.1 * _rand(D, seed=29)
+    nw, nb = 1 + 0.1 * _rand(D, seed=30), 0.1 * _rand(D, seed=31)
+    x = tok.clone()
+    ops.embed_finalize(x, B, N, D, cls, pos, ew, eb, 1e-5, nw, nb, 1e-5)
+    t = tok.double().view(B, N, D).clone()
+    t[:, 1:] = F.layer_norm(t[:, 1:], (D,), ew.double(), eb.double(), 1e-5)
+    t[:, 0] = cls.double()
+    ref = F.layer_norm(t, (D,), nw.double(), nb.double(), 1e-5) + pos.double()
+    assert _rel(x.view(B, N, D), ref) <= 1e-5
+    out = torch.empty_like(tok)
+    ops.layernorm(tok, out, B * N, D, nw, nb, 1e-5)
+    assert _rel(out, F.layer_norm(tok.double(), (D,), nw.double(), nb.double(), 1e-5)) <= 1e-5
+    g = _rand(D, seed=33)
+    ops.scale_channels(tok, out, B * N, D, g)
+    assert torch.equal(out, tok * g)
+
+
+def _build(name, seed, param_dtype=torch.float32):
+    from vitm_amd.models import VisionTransformer, VITC
+    cfg = W.CONFIGS[name]
+    LN = nn.LayerNorm
+    vt = VisionTransformer(cfg["image_size"], patch_size=cfg["patch_size"], num_classes=cfg["num_classes"],
+                           num_heads=cfg["num_heads"], mlp_ratio=cfg["mlp_ratio"], depth=cfg["depth"],
+                           embed_dim=cfg["embed_dim"], norm_layer=LN,
+                           embed_norm_layer=LN if cfg["embed_norm"] else None,
+                           final_norm_layer=LN if cfg["final_norm"] else None)
+    m = VITC(vt).eval()
+    sd = {k: torch.from_numpy(v) for k, v in W.make_state_dict(cfg, seed).items()}
+    m.load_state_dict(sd, strict=True)
+    return m.to(device=DEV, dtype=param_dtype), sd, cfg
+
+
+@pytest.mark.parametrize("name", ["tiny2", "vit_tiny_cifar", "cifar_recipe", "vit_s16", "vit_b16", "vit_b16_384"])
+def test_model_fp32_matches_reference_golden(name):
+    g = np.load(os.path.join(GOLD, f"{name}.npz"))
+    seed, batch = int(g["seed"]), int(g["batch"])
+    model, sd, cfg = _build(name, seed)
+    x = torch.from_numpy(W.make_input(cfg, batch, seed + 1)).to(DEV)
+    with torch.no_grad():
+        logits = model(x)
+        emb = model.vit_model(x)
+    assert logits.dtype == torch.float32 and emb.dtype == torch.float32
+    assert _rel(logits.cpu(), torch.from_numpy(g["logits"])) <= REL, name
+    got = emb.cpu()
+    if "embeddings_rows" in g:
+        got = got[:, torch.from_numpy(g["embeddings_rows"])]
+    assert _rel(got, torch.from_numpy(g["embeddings"])) <= REL, name
+
+
+def test_cifar_vit_tiny_batch64_fp32_matches_oracle():
+    """The reference's CPU-runnable configuration: ViT-tiny on 32x32 CIFAR images, patch 4, batch 64, fp32."""
+    from oracle import vit_oracle as O
+    model, sd, cfg = _build("vit_tiny_cifar", seed=11)
+    x = torch.from_numpy(W.make_input(cfg, 64, 12))
+    ref = O.vitc_forward(x, sd, W.oracle_cfg(cfg))
+    with torch.no_grad():
+        got = model(x.to(DEV))
+    assert got.shape == (64, cfg["num_classes"])
+    assert _rel(got.cpu(), ref) <= REL
+
+
+def test_fp32_input_with_bf16_parameters_uses_fp32_arithmetic():
+    """Parameters stored in bf16 are widened exactly; the arithmetic is still fp32."""
+    from oracle import vit_oracle as O
+    model, sd, cfg = _build("tiny2", seed=3, param_dtype=torch.bfloat16)
+    sd_r = {k: v.to(torch.bfloat16).float() for k, v in sd.items()}
+    x = torch.from_numpy(W.make_input(cfg, 4, 5))
+    ref = O.vitc_forward(x, sd_r, W.oracle_cfg(cfg))
+    with torch.no_grad():
+        got = model(x.to(DEV))
+    assert got.dtype == torch.float32
+    assert _rel(got.cpu(), ref) <= REL

@@ -109,8 +109,8 @@ __global__ __launch_bounds__(256) void ln_stats_kernel(const T* __restrict__ x, 
   if (lane == 0) *(float2*)(stats + 2 * (int64_t)m) = make_float2(mean, rstd);
 }
 
-template <typename TO>
-__global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict__ x, int64_t ldx,
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void layernorm_kernel(const TI* __restrict__ x, int64_t ldx,
                                                         TO* __restrict__ out, int64_t ldo, int M, int D,
                                                         const float* __restrict__ w,
                                                         const float* __restrict__ b, float eps) {
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict
   const int m = blockIdx.x * ROWS_PER_WG + (threadIdx.x >> 6);
   if (m >= M) return;
   Row r;
-  load_row<bf16_t>(r, x + (int64_t)m * ldx, D, lane);
+  load_row<TI>(r, x + (int64_t)m * ldx, D, lane);
   float mean, rstd;
   row_stats(r, D, lane, eps, mean, rstd);
   normalize_row(r, D, lane, mean, rstd, w, b);
@@ -130,7 +130,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict
   }
 }
 
-__global__ __launch_bounds__(256) void embed_finalize_kernel(bf16_t* __restrict__ x, int64_t ldx, int rows,
+template <typename T>
+__global__ __launch_bounds__(256) void embed_finalize_kernel(T* __restrict__ x, int64_t ldx, int rows,
                                                              int ntok, int D, const float* __restrict__ cls,
                                                              const float* __restrict__ pos,
                                                              const float* __restrict__ en_w,
@@ -141,13 +142,13 @@ __global__ __launch_bounds__(256) void embed_finalize_kernel(bf16_t* __restrict_
   const int m = blockIdx.x * ROWS_PER_WG + (threadIdx.x >> 6);
   if (m >= rows) return;
   const int n = m % ntok;
-  bf16_t* xr = x + (int64_t)m * ldx;
+  T* xr = x + (int64_t)m * ldx;
   Row r;
   float mean, rstd;
   if (n == 0 && cls != nullptr) {
     load_row<float>(r, cls, D, lane);
   } else {
-    load_row<bf16_t>(r, xr, D, lane);
+    load_row<T>(r, xr, D, lane);
     if (en_w != nullptr) {  // PatchEmbed.norm_layer acts on patch tokens only
       row_stats(r, D, lane, en_eps, mean, rstd);
       normalize_row(r, D, lane, mean, rstd, en_w, en_b);
@@ -172,8 +173,9 @@ __global__ __launch_bounds__(256) void embed_finalize_kernel(bf16_t* __restrict_
   }
 }
 
-__global__ __launch_bounds__(256) void scale_channels_kernel(const bf16_t* __restrict__ x, int64_t ldx,
-                                                             bf16_t* __restrict__ out, int64_t ldo, int M,
+template <typename T>
+__global__ __launch_bounds__(256) void scale_channels_kernel(const T* __restrict__ x, int64_t ldx,
+                                                             T* __restrict__ out, int64_t ldo, int M,
                                                              int D, const float* __restrict__ gamma) {
   const int cpr = D / 8;
   const int64_t total = (int64_t)M * cpr;
@@ -181,7 +183,7 @@ __global__ __launch_bounds__(256) void scale_channels_kernel(const bf16_t* __res
     const int64_t m = i / cpr;
     const int c = (int)(i - m * cpr) * 8;
     float v[8], g[8];
-    load8<bf16_t>(x + m * ldx + c, v);
+    load8<T>(x + m * ldx + c, v);
     load8<float>(gamma + c, g);
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] *= g[e];
@@ -198,29 +200,30 @@ __device__ __forceinline__ float block_sum_256(float v, float* sh) {
 }
 
 // one workgroup per output row n
-template <typename TW>
+template <typename TW, typename TP>
 __global__ __launch_bounds__(256) void prepack_linear_kernel(const TW* __restrict__ w, const float* __restrict__ bias,
                                                              const float* __restrict__ ln_g,
                                                              const float* __restrict__ ln_b,
                                                              const float* __restrict__ oscale, int K, int kpad,
-                                                             bf16_t* __restrict__ wp, float* __restrict__ s,
+                                                             TP* __restrict__ wp, float* __restrict__ s,
                                                              float* __restrict__ c, float* __restrict__ g) {
   __shared__ float sh[4];
   const int n = blockIdx.x;
   const TW* wr = w + (int64_t)n * K;
-  bf16_t* wo = wp + (int64_t)n * kpad;
+  TP* wo = wp + (int64_t)n * kpad;
   float ssum = 0.f, csum = 0.f;
   for (int k = threadIdx.x; k < kpad; k += 256) {
-    bf16_t o = 0;
+    float o = 0.f;   // the value as the GEMM will see it (rounded to the packed type)
     if (k < K) {
       float wv;
       if (sizeof(TW) == 2) wv = bf2f(*(const bf16_t*)(wr + k)); else wv = *(const float*)(wr + k);
       const float gk = ln_g ? ln_g[k] : 1.0f;
-      o = f2bf(wv * gk);
-      ssum += bf2f(o);
+      o = wv * gk;
+      if (sizeof(TP) == 2) o = bf2f(f2bf(o));
+      ssum += o;
       if (ln_b) csum = fmaf(ln_b[k], wv, csum);
     }
-    wo[k] = o;
+    if (sizeof(TP) == 2) *(bf16_t*)(wo + k) = f2bf(o); else *(float*)(wo + k) = o;
   }
   ssum = block_sum_256(ssum, sh);
   csum = block_sum_256(csum, sh);
@@ -278,67 +281,84 @@ extern "C" int vitm_ln_stats(const void* x, int x_dtype, int64_t ldx, int M, int
   return VITM_OK;
 }
 
-extern "C" int vitm_layernorm(const void* x, int64_t ldx, void* out, int out_dtype, int64_t ldo, int M, int D,
-                              const float* w, const float* b, float eps, vitm_stream_t stream) {
+extern "C" int vitm_layernorm(const void* x, int x_dtype, int64_t ldx, void* out, int out_dtype, int64_t ldo, int M,
+                              int D, const float* w, const float* b, float eps, vitm_stream_t stream) {
   VITM_REQUIRE(x && out && w && b, "vitm_layernorm: null pointer");
   VITM_REQUIRE(M > 0 && D > 0 && D % 8 == 0 && D <= MAXD, "vitm_layernorm: D=%d must be a multiple of 8 and <= %d", D, MAXD);
   VITM_REQUIRE(ldx >= D && ldo >= D && ldx % 8 == 0 && ldo % 8 == 0 && al16(x) && al16(out) && al16(w) && al16(b),
                "vitm_layernorm: leading dimensions must be multiples of 8 and pointers 16-byte aligned");
+  VITM_REQUIRE((x_dtype == VITM_BF16 || x_dtype == VITM_F32) && (out_dtype == VITM_BF16 || out_dtype == VITM_F32),
+               "vitm_layernorm: bad dtype (x %d, out %d)", x_dtype, out_dtype);
   hipStream_t st = (hipStream_t)stream;
-  if (out_dtype == VITM_BF16) {
-    hipLaunchKernelGGL(layernorm_kernel<bf16_t>, dim3(row_grid(M)), dim3(256), 0, st, (const bf16_t*)x, ldx, (bf16_t*)out, ldo, M, D, w, b, eps);
-  } else if (out_dtype == VITM_F32) {
-    hipLaunchKernelGGL(layernorm_kernel<float>, dim3(row_grid(M)), dim3(256), 0, st, (const bf16_t*)x, ldx, (float*)out, ldo, M, D, w, b, eps);
+  const dim3 grid(row_grid(M)), blk(256);
+  if (x_dtype == VITM_BF16 && out_dtype == VITM_BF16) {
+    hipLaunchKernelGGL((layernorm_kernel<bf16_t, bf16_t>), grid, blk, 0, st, (const bf16_t*)x, ldx, (bf16_t*)out, ldo, M, D, w, b, eps);
+  } else if (x_dtype == VITM_BF16) {
+    hipLaunchKernelGGL((layernorm_kernel<bf16_t, float>), grid, blk, 0, st, (const bf16_t*)x, ldx, (float*)out, ldo, M, D, w, b, eps);
+  } else if (out_dtype == VITM_BF16) {
+    hipLaunchKernelGGL((layernorm_kernel<float, bf16_t>), grid, blk, 0, st, (const float*)x, ldx, (bf16_t*)out, ldo, M, D, w, b, eps);
   } else {
-    vitm_set_error("vitm_layernorm: bad out_dtype %d", out_dtype);
-    return VITM_EINVAL;
+    hipLaunchKernelGGL((layernorm_kernel<float, float>), grid, blk, 0, st, (const float*)x, ldx, (float*)out, ldo, M, D, w, b, eps);
   }
   VITM_CHECK_LAUNCH("vitm_layernorm");
   return VITM_OK;
 }
 
-extern "C" int vitm_embed_finalize(void* x, int64_t ldx, int B, int ntok, int D, const float* cls,
+extern "C" int vitm_embed_finalize(void* x, int x_dtype, int64_t ldx, int B, int ntok, int D, const float* cls,
                                    const float* pos, const float* en_w, const float* en_b, float en_eps,
                                    const float* np_w, const float* np_b, float np_eps, vitm_stream_t stream) {
   VITM_REQUIRE(x, "vitm_embed_finalize: null x");
+  VITM_REQUIRE(x_dtype == VITM_BF16 || x_dtype == VITM_F32, "vitm_embed_finalize: bad x_dtype %d", x_dtype);
   VITM_REQUIRE(B > 0 && ntok > 0 && D > 0 && D % 8 == 0 && D <= MAXD, "vitm_embed_finalize: D=%d must be a multiple of 8 and <= %d", D, MAXD);
   VITM_REQUIRE(ldx >= D && ldx % 8 == 0 && al16(x), "vitm_embed_finalize: ldx/alignment");
   VITM_REQUIRE((en_w == nullptr) == (en_b == nullptr) && (np_w == nullptr) == (np_b == nullptr),
                "vitm_embed_finalize: LayerNorm weight and bias must be given together");
   VITM_REQUIRE(al16(cls) && al16(pos) && al16(en_w) && al16(en_b) && al16(np_w) && al16(np_b), "vitm_embed_finalize: vectors must be 16-byte aligned");
   const int rows = B * ntok;
-  hipLaunchKernelGGL(embed_finalize_kernel, dim3(row_grid(rows)), dim3(256), 0, (hipStream_t)stream, (bf16_t*)x, ldx, rows,
-                     ntok, D, cls, pos, en_w, en_b, en_eps, np_w, np_b, np_eps);
+  if (x_dtype == VITM_BF16) {
+    hipLaunchKernelGGL(embed_finalize_kernel<bf16_t>, dim3(row_grid(rows)), dim3(256), 0, (hipStream_t)stream, (bf16_t*)x, ldx,
+                       rows, ntok, D, cls, pos, en_w, en_b, en_eps, np_w, np_b, np_eps);
+  } else {
+    hipLaunchKernelGGL(embed_finalize_kernel<float>, dim3(row_grid(rows)), dim3(256), 0, (hipStream_t)stream, (float*)x, ldx,
+                       rows, ntok, D, cls, pos, en_w, en_b, en_eps, np_w, np_b, np_eps);
+  }
   VITM_CHECK_LAUNCH("vitm_embed_finalize");
   return VITM_OK;
 }
 
-extern "C" int vitm_scale_channels(const void* x, int64_t ldx, void* out, int64_t ldo, int M, int D,
+extern "C" int vitm_scale_channels(const void* x, int64_t ldx, void* out, int64_t ldo, int dtype, int M, int D,
                                    const float* gamma, vitm_stream_t stream) {
   VITM_REQUIRE(x && out && gamma, "vitm_scale_channels: null pointer");
+  VITM_REQUIRE(dtype == VITM_BF16 || dtype == VITM_F32, "vitm_scale_channels: bad dtype %d", dtype);
   VITM_REQUIRE(M > 0 && D > 0 && D % 8 == 0 && ldx >= D && ldo >= D && ldx % 8 == 0 && ldo % 8 == 0, "vitm_scale_channels: D/ld must be multiples of 8");
   VITM_REQUIRE(al16(x) && al16(out) && al16(gamma), "vitm_scale_channels: pointers must be 16-byte aligned");
-  hipLaunchKernelGGL(scale_channels_kernel, dim3(stream_grid((int64_t)M * (D / 8))), dim3(256), 0, (hipStream_t)stream,
-                     (const bf16_t*)x, ldx, (bf16_t*)out, ldo, M, D, gamma);
+  const dim3 grid(stream_grid((int64_t)M * (D / 8)));
+  if (dtype == VITM_BF16) {
+    hipLaunchKernelGGL(scale_channels_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, (bf16_t*)out, ldo, M, D, gamma);
+  } else {
+    hipLaunchKernelGGL(scale_channels_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)x, ldx, (float*)out, ldo, M, D, gamma);
+  }
   VITM_CHECK_LAUNCH("vitm_scale_channels");
   return VITM_OK;
 }
 
 extern "C" int vitm_prepack_linear(const void* w, int w_dtype, const float* bias, const float* ln_gamma,
                                    const float* ln_beta, const float* out_scale, int N, int K, int kpad,
-                                   void* wp, float* s, float* c, float* g, vitm_stream_t stream) {
+                                   void* wp, int wp_dtype, float* s, float* c, float* g, vitm_stream_t stream) {
   VITM_REQUIRE(w && wp && c, "vitm_prepack_linear: null w/wp/c");
   VITM_REQUIRE(N > 0 && K > 0 && kpad >= K, "vitm_prepack_linear: bad N/K/kpad");
+  VITM_REQUIRE((w_dtype == VITM_BF16 || w_dtype == VITM_F32) && (wp_dtype == VITM_BF16 || wp_dtype == VITM_F32),
+               "vitm_prepack_linear: bad dtype (w %d, wp %d)", w_dtype, wp_dtype);
   hipStream_t st = (hipStream_t)stream;
-  if (w_dtype == VITM_F32) {
-    hipLaunchKernelGGL(prepack_linear_kernel<float>, dim3((unsigned)N), dim3(256), 0, st, (const float*)w, bias, ln_gamma, ln_beta,
-                       out_scale, K, kpad, (bf16_t*)wp, s, c, g);
-  } else if (w_dtype == VITM_BF16) {
-    hipLaunchKernelGGL(prepack_linear_kernel<bf16_t>, dim3((unsigned)N), dim3(256), 0, st, (const bf16_t*)w, bias, ln_gamma, ln_beta,
-                       out_scale, K, kpad, (bf16_t*)wp, s, c, g);
+  const dim3 grid((unsigned)N), blk(256);
+  if (w_dtype == VITM_F32 && wp_dtype == VITM_BF16) {
+    hipLaunchKernelGGL((prepack_linear_kernel<float, bf16_t>), grid, blk, 0, st, (const float*)w, bias, ln_gamma, ln_beta, out_scale, K, kpad, (bf16_t*)wp, s, c, g);
+  } else if (w_dtype == VITM_BF16 && wp_dtype == VITM_BF16) {
+    hipLaunchKernelGGL((prepack_linear_kernel<bf16_t, bf16_t>), grid, blk, 0, st, (const bf16_t*)w, bias, ln_gamma, ln_beta, out_scale, K, kpad, (bf16_t*)wp, s, c, g);
+  } else if (w_dtype == VITM_F32) {
+    hipLaunchKernelGGL((prepack_linear_kernel<float, float>), grid, blk, 0, st, (const float*)w, bias, ln_gamma, ln_beta, out_scale, K, kpad, (float*)wp, s, c, g);
   } else {
-    vitm_set_error("vitm_prepack_linear: bad w_dtype %d", w_dtype);
-    return VITM_EINVAL;
+    hipLaunchKernelGGL((prepack_linear_kernel<bf16_t, float>), grid, blk, 0, st, (const bf16_t*)w, bias, ln_gamma, ln_beta, out_scale, K, kpad, (float*)wp, s, c, g);
   }
   VITM_CHECK_LAUNCH("vitm_prepack_linear");
   return VITM_OK;

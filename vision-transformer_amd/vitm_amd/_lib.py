@@ -32,18 +32,24 @@ SIGNATURES = {
     "vitm_last_error": (c_char_p, []),
     "vitm_gemm_k_multiple": (c_int, []),
     "vitm_prepack_linear": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
-                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+                                    c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "vitm_ln_stats": (c_int, [c_void_p, c_int, c_int64, c_int, c_int, c_float, c_void_p, c_void_p]),
     "vitm_gemm": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int,
                           c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "vitm_patch_embed": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int64, c_int,
                                  c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
-    "vitm_embed_finalize": (c_int, [c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+    "vitm_gemm_f32": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_int,
+                              c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+    "vitm_patch_embed_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int64,
+                                     c_int, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
+    "vitm_embed_finalize": (c_int, [c_void_p, c_int, c_int64, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                     c_float, c_void_p, c_void_p, c_float, c_void_p]),
     "vitm_attention": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_float, c_void_p]),
-    "vitm_layernorm": (c_int, [c_void_p, c_int64, c_void_p, c_int, c_int64, c_int, c_int, c_void_p, c_void_p,
+    "vitm_attention_f32": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_float,
+                                   c_void_p]),
+    "vitm_layernorm": (c_int, [c_void_p, c_int, c_int64, c_void_p, c_int, c_int64, c_int, c_int, c_void_p, c_void_p,
                                c_float, c_void_p]),
-    "vitm_scale_channels": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p]),
+    "vitm_scale_channels": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_void_p]),
     "vitm_cast_f32_to_bf16": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "vitm_cast_bf16_to_f32": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
 }

@@ -46,24 +46,49 @@ def _dt(t: torch.Tensor) -> int:
 
 
 def f32vec(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
-    """A parameter vector as a contiguous fp32 tensor (no copy when it already is one)."""
+    """A parameter vector as a contiguous fp32 tensor: no copy when it already is one, otherwise a copy that is
+    memoised on the tensor until its storage or version changes (so a bf16 module converts once, not per call)."""
     if t is None:
         return None
-    return t.detach().to(torch.float32).contiguous()
+    d = t.detach()
+    if d.dtype == torch.float32 and d.is_contiguous():
+        return d
+    key = (t.data_ptr(), t._version, t.dtype, t.device, tuple(t.shape))
+    hit = getattr(t, "_vitm_f32", None)
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    val = d.to(torch.float32).contiguous()
+    try:
+        t._vitm_f32 = (key, val)
+    except AttributeError:  # pragma: no cover - tensors that refuse attributes just convert every time
+        pass
+    return val
 
 
 class PackedLinear:
-    """bf16 weight [npad, kpad] (+ folded LayerNorm / LayerScale vectors) ready for vitm_gemm."""
+    """Packed weight [npad, kpad] (bf16 for vitm_gemm, fp32 for vitm_gemm_f32) plus the folded LayerNorm /
+    LayerScale vectors."""
     __slots__ = ("wp", "s", "c", "g", "N", "K", "npad", "kpad")
 
     def __init__(self, wp, s, c, g, N, K, npad, kpad):
         self.wp, self.s, self.c, self.g = wp, s, c, g
         self.N, self.K, self.npad, self.kpad = N, K, npad, kpad
 
+    @property
+    def dtype(self):
+        return self.wp.dtype
+
+
+def compute_dtype(x: torch.Tensor) -> torch.dtype:
+    """The arithmetic path a tensor takes: fp32 tensors run the fp32 kernels, bf16 tensors the bf16 ones."""
+    if x.dtype in (torch.float32, torch.bfloat16):
+        return x.dtype
+    raise TypeError(f"unsupported activation dtype {x.dtype} (bf16 or fp32)")
+
 
 def pack_linear(weight: torch.Tensor, bias: Optional[torch.Tensor] = None,
                 ln_weight: Optional[torch.Tensor] = None, ln_bias: Optional[torch.Tensor] = None,
-                out_scale: Optional[torch.Tensor] = None) -> PackedLinear:
+                out_scale: Optional[torch.Tensor] = None, dtype: torch.dtype = torch.bfloat16) -> PackedLinear:
     """Run vitm_prepack_linear on an (N, K...) weight; N is padded to 8 and K to the GEMM's K multiple."""
     lib = _lib.load()
     w = weight.detach()
@@ -73,7 +98,7 @@ def pack_linear(weight: torch.Tensor, bias: Optional[torch.Tensor] = None,
     N, K = w.shape
     npad, kpad = round_up(N, 8), round_up(K, k_multiple())
     dev = w.device
-    wp = torch.zeros((npad, kpad), dtype=torch.bfloat16, device=dev)
+    wp = torch.zeros((npad, kpad), dtype=dtype, device=dev)
     fold_ln = ln_weight is not None
     s = torch.zeros(npad, dtype=torch.float32, device=dev) if fold_ln else None
     c = torch.zeros(npad, dtype=torch.float32, device=dev)
@@ -82,7 +107,7 @@ def pack_linear(weight: torch.Tensor, bias: Optional[torch.Tensor] = None,
     if fold_ln and lb32 is None:
         lb32 = torch.zeros_like(lw32)
     _lib.check(lib.vitm_prepack_linear(_p(w), _dt(w), _p(b32), _p(lw32), _p(lb32), _p(os32), N, K, kpad,
-                                       _p(wp), _p(s), _p(c), _p(g), _stream()), "vitm_prepack_linear")
+                                       _p(wp), _dt(wp), _p(s), _p(c), _p(g), _stream()), "vitm_prepack_linear")
     return PackedLinear(wp, s, c, g, N, K, npad, kpad)
 
 
@@ -109,9 +134,19 @@ def ln_stats(x: torch.Tensor, M: int, D: int, eps: float, stats: Optional[torch.
 
 def gemm(A: torch.Tensor, pk: PackedLinear, out: torch.Tensor, epilogue: int, M: int,
          stats: Optional[torch.Tensor] = None, resid: Optional[torch.Tensor] = None, row_group: int = 0) -> torch.Tensor:
-    """out[:, :npad] = epilogue(A[:, :kpad] . wp^T); A, out (and resid) are 2-D row-major views."""
-    assert A.dtype == torch.bfloat16 and A.stride(1) == 1 and out.stride(1) == 1
+    """out[:, :npad] = epilogue(A[:, :kpad] . wp^T); A, out (and resid) are 2-D row-major views.
+    fp32 A runs the fp32 kernel (fp32 packed weight, fp32 out and resid)."""
+    assert A.stride(1) == 1 and out.stride(1) == 1
     assert A.shape[1] >= pk.kpad, "A operand narrower than the packed K"
+    assert A.dtype == pk.dtype, f"A is {A.dtype} but the weight was packed as {pk.dtype}"
+    if A.dtype == torch.float32:
+        assert out.dtype == torch.float32 and (resid is None or resid.dtype == torch.float32)
+        _lib.check(_lib.load().vitm_gemm_f32(
+            _p(A), A.stride(0), _p(pk.wp), pk.kpad, _p(out), out.stride(0), M, pk.npad, pk.kpad, epilogue,
+            _p(pk.c), _p(pk.g), _p(resid), 0 if resid is None else resid.stride(0), row_group, _stream()),
+            "vitm_gemm_f32")
+        return out
+    assert A.dtype == torch.bfloat16
     _lib.check(_lib.load().vitm_gemm(
         _p(A), A.stride(0), _p(pk.wp), pk.kpad, _p(out), out.stride(0), _dt(out), M, pk.npad, pk.kpad, epilogue,
         _p(stats), _p(pk.s), _p(pk.c), _p(pk.g), _p(resid), 0 if resid is None else resid.stride(0), row_group,
@@ -121,6 +156,12 @@ def gemm(A: torch.Tensor, pk: PackedLinear, out: torch.Tensor, epilogue: int, M:
 
 def patch_embed(img: torch.Tensor, pk: PackedLinear, tokens: torch.Tensor, patch, D: int, cls_slot: bool) -> None:
     B, C, H, W = img.shape
+    if tokens.dtype == torch.float32:
+        assert pk.dtype == torch.float32
+        _lib.check(_lib.load().vitm_patch_embed_f32(
+            _p(img), _dt(img), B, C, H, W, patch[0], patch[1], _p(pk.wp), pk.kpad, pk.kpad, _p(pk.c), _p(tokens),
+            tokens.stride(0), D, 1 if cls_slot else 0, _stream()), "vitm_patch_embed_f32")
+        return
     _lib.check(_lib.load().vitm_patch_embed(
         _p(img), _dt(img), B, C, H, W, patch[0], patch[1], _p(pk.wp), pk.kpad, pk.kpad, _p(pk.c), _p(tokens),
         tokens.stride(0), D, 1 if cls_slot else 0, _stream()), "vitm_patch_embed")
@@ -128,23 +169,29 @@ def patch_embed(img: torch.Tensor, pk: PackedLinear, tokens: torch.Tensor, patch
 
 def embed_finalize(x: torch.Tensor, B: int, ntok: int, D: int, cls, pos, en_w, en_b, en_eps, np_w, np_b, np_eps) -> None:
     _lib.check(_lib.load().vitm_embed_finalize(
-        _p(x), x.stride(0), B, ntok, D, _p(cls), _p(pos), _p(en_w), _p(en_b), float(en_eps), _p(np_w), _p(np_b),
+        _p(x), _dt(x), x.stride(0), B, ntok, D, _p(cls), _p(pos), _p(en_w), _p(en_b), float(en_eps), _p(np_w), _p(np_b),
         float(np_eps), _stream()), "vitm_embed_finalize")
 
 
 def attention(qkv: torch.Tensor, out: torch.Tensor, B: int, N: int, H: int, hd: int, scale: float) -> None:
+    assert qkv.dtype == out.dtype
+    if qkv.dtype == torch.float32:
+        _lib.check(_lib.load().vitm_attention_f32(_p(qkv), qkv.stride(0), _p(out), out.stride(0), B, N, H, hd,
+                                                  float(scale), _stream()), "vitm_attention_f32")
+        return
     _lib.check(_lib.load().vitm_attention(_p(qkv), qkv.stride(0), _p(out), out.stride(0), B, N, H, hd, float(scale),
                                           _stream()), "vitm_attention")
 
 
 def layernorm(x: torch.Tensor, out: torch.Tensor, M: int, D: int, w: torch.Tensor, b: torch.Tensor, eps: float) -> None:
-    _lib.check(_lib.load().vitm_layernorm(_p(x), x.stride(0), _p(out), _dt(out), out.stride(0), M, D, _p(w), _p(b),
+    _lib.check(_lib.load().vitm_layernorm(_p(x), _dt(x), x.stride(0), _p(out), _dt(out), out.stride(0), M, D, _p(w), _p(b),
                                           float(eps), _stream()), "vitm_layernorm")
 
 
 def scale_channels(x: torch.Tensor, out: torch.Tensor, M: int, D: int, gamma: torch.Tensor) -> None:
-    _lib.check(_lib.load().vitm_scale_channels(_p(x), x.stride(0), _p(out), out.stride(0), M, D, _p(gamma), _stream()),
-               "vitm_scale_channels")
+    assert x.dtype == out.dtype
+    _lib.check(_lib.load().vitm_scale_channels(_p(x), x.stride(0), _p(out), out.stride(0), _dt(x), M, D, _p(gamma),
+                                               _stream()), "vitm_scale_channels")
 
 
 def to_bf16(x: torch.Tensor) -> torch.Tensor:
@@ -170,6 +217,8 @@ def to_f32(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def like_input(y_bf16: torch.Tensor, ref: torch.Tensor) -> torch.Tensor:
-    """Return the bf16 result in the caller's dtype (fp32 callers get an fp32 tensor back)."""
-    return to_f32(y_bf16) if ref.dtype == torch.float32 else y_bf16
+def like_input(y: torch.Tensor, ref: torch.Tensor) -> torch.Tensor:
+    """Return a result in the caller's dtype (a cast kernel only when the two differ)."""
+    if y.dtype == ref.dtype:
+        return y
+    return to_f32(y) if ref.dtype == torch.float32 else to_bf16(y)

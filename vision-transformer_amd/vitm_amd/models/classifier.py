@@ -3,7 +3,7 @@
 API mirror of the reference's ``VITC`` (vitm/models/classifier.py:6-39): ``VITC(vit_model)`` with
 attributes ``vit_model`` and ``head = nn.Linear(embed_dim, num_classes)`` and state_dict keys
 ``vit_model.*``, ``head.{weight,bias}``.  When the backbone is this package's ``VisionTransformer`` the final
-LayerNorm is applied to the class-token rows only and folded into the head GEMM.
+LayerNorm is applied to the class-token rows only (folded into the head GEMM on the bf16 path).
 """
 from __future__ import annotations
 
@@ -28,29 +28,37 @@ class VITC(nn.Module):
         C = self.head.out_features
         with torch.cuda.device(x.device):
             if isinstance(vt, VisionTransformer):
-                x2d, B, N, D = vt._run_blocks(x)              # pre-final-norm tokens, rows (b, n), bf16
+                x2d, B, N, D = vt._run_blocks(x)              # pre-final-norm tokens, rows (b, n)
                 cls_rows = x2d.view(B, N, x2d.shape[1])[:, 0]  # (B, ld) view with row stride N*ld
                 ln = layernorm_params(vt.norm_final, "VisionTransformer.norm_final")
             else:                                             # foreign backbone: take its output as is
                 emb = vt(x)
                 B, N, D = emb.shape
-                cls_rows = _ops.to_bf16(emb[:, 0].contiguous())
+                _ops.compute_dtype(emb)
+                cls_rows = emb[:, 0].contiguous()
                 kp = _ops.round_up(D, _ops.k_multiple())
                 if kp != D:
-                    pad = torch.zeros((B, kp), dtype=torch.bfloat16, device=x.device)
+                    pad = torch.zeros((B, kp), dtype=emb.dtype, device=x.device)
                     pad[:, :D] = cls_rows
                     cls_rows = pad
                 ln = None
             w, b = self.head.weight, self.head.bias
-            out_dtype = torch.float32 if x.dtype == torch.float32 else torch.bfloat16
+            dt = cls_rows.dtype
+            f32 = dt == torch.float32
+            tag = "f32" if f32 else "bf16"
+            if ln is not None and f32:                        # fp32: explicit LayerNorm of the class rows
+                normed = torch.zeros((B, cls_rows.shape[1]), dtype=dt, device=x.device)
+                _ops.layernorm(cls_rows, normed, B, D, _ops.f32vec(ln[0]), _ops.f32vec(ln[1]), ln[2])
+                cls_rows, ln = normed, None
+            # logits: bf16 for bf16 callers, fp32 for fp32 callers
             if ln is not None:
-                pk = _ops.cached_pack(self, "head_ln", (w, b, ln[0], ln[1]),
-                                      lambda: _ops.pack_linear(w, b, ln[0], ln[1]))
+                pk = _ops.cached_pack(self, "head_ln_" + tag, (w, b, ln[0], ln[1]),
+                                      lambda: _ops.pack_linear(w, b, ln[0], ln[1], dtype=dt))
                 stats = _ops.ln_stats(cls_rows, B, D, ln[2])
-                logits = torch.empty((B, pk.npad), dtype=out_dtype, device=x.device)
+                logits = torch.empty((B, pk.npad), dtype=dt, device=x.device)
                 _ops.gemm(cls_rows, pk, logits, _ops.EPI_LN, B, stats=stats)
             else:
-                pk = _ops.cached_pack(self, "head", (w, b), lambda: _ops.pack_linear(w, b))
-                logits = torch.empty((B, pk.npad), dtype=out_dtype, device=x.device)
+                pk = _ops.cached_pack(self, "head_" + tag, (w, b), lambda: _ops.pack_linear(w, b, dtype=dt))
+                logits = torch.empty((B, pk.npad), dtype=dt, device=x.device)
                 _ops.gemm(cls_rows, pk, logits, _ops.EPI_BIAS, B)
             return logits[:, :C]

@@ -4,8 +4,10 @@ API mirror of the reference's vitm/models/models.py -- ``Attention`` (:27-95), `
 ``LayerScale`` (:132-139), ``Block`` (:142-211), ``VisionTransformer`` (:215-416) -- with the same
 constructor arguments, attribute names and state_dict keys, so reference checkpoints load with
 ``load_state_dict(strict=True)``.  Every ``forward`` is a short sequence of C-ABI calls
-(include/vitm_gfx950.h); activations travel as bf16 with fp32 accumulation and come back in the dtype of
-the input.  The path is forward-only (no autograd graph is recorded).
+(include/vitm_gfx950.h).  The arithmetic follows the input's dtype: bf16 tensors run the bf16 MFMA kernels
+(fp32 accumulation, LayerNorm folded into the next GEMM), fp32 tensors run the fp32 kernels (fp32 MFMA,
+explicit LayerNorm, erf-accurate GELU); parameters may be stored in either dtype.  The path is forward-only
+(no autograd graph is recorded).
 
 Deliberate differences from the reference's HEAD, all supersets of what can run there:
   * ``forward_heads`` iterates ``self.blocks`` (the reference calls the ModuleList, models.py:409, which raises);
@@ -35,23 +37,33 @@ def _check_gelu(act: nn.Module, what: str) -> None:
 
 
 def _as_rows(x: torch.Tensor, D: int) -> Tuple[torch.Tensor, int]:
-    """(..., D) CUDA activation -> contiguous bf16 [M, kpad(D)] (pad columns zero) and M."""
+    """(..., D) CUDA activation -> contiguous [M, kpad(D)] in its compute dtype (pad columns zero) and M."""
     M = x.numel() // D
-    xb = _ops.to_bf16(x.reshape(M, D))
+    _ops.compute_dtype(x)
+    xb = x.reshape(M, D).contiguous()
     kp = _ops.round_up(D, _ops.k_multiple())
     if kp != D:
-        padded = torch.zeros((M, kp), dtype=torch.bfloat16, device=x.device)
+        padded = torch.zeros((M, kp), dtype=x.dtype, device=x.device)
         padded[:, :D] = xb
         xb = padded
     return xb, M
 
 
-def _act_buffer(M: int, width: int, device, zero_pad_from: Optional[int] = None) -> torch.Tensor:
-    """bf16 [M, kpad(width)] activation buffer; zero-filled when it has pad columns a later GEMM reads."""
+def _act_buffer(M: int, width: int, device, dtype, zero_pad_from: Optional[int] = None) -> torch.Tensor:
+    """[M, kpad(width)] activation buffer; zero-filled when it has pad columns a later GEMM reads."""
     kp = _ops.round_up(width, _ops.k_multiple())
     if kp != (zero_pad_from if zero_pad_from is not None else width):
-        return torch.zeros((M, kp), dtype=torch.bfloat16, device=device)
-    return torch.empty((M, kp), dtype=torch.bfloat16, device=device)
+        return torch.zeros((M, kp), dtype=dtype, device=device)
+    return torch.empty((M, kp), dtype=dtype, device=device)
+
+
+def _pack(owner, slot: str, dtype, w, b, ln=None, gamma=None) -> _ops.PackedLinear:
+    """Packed form of Linear (w, b) for ``dtype`` arithmetic, with an optional folded LayerNorm (weight, bias, eps)
+    in front and LayerScale vector behind; memoised on ``owner`` until a source tensor changes."""
+    lw, lb = (ln[0], ln[1]) if ln is not None else (None, None)
+    tag = f"{slot}{'_ln' if ln is not None else ''}{'_ls' if gamma is not None else ''}_{'f32' if dtype == torch.float32 else 'bf16'}"
+    return _ops.cached_pack(owner, tag, (w, b, lw, lb, gamma),
+                            lambda: _ops.pack_linear(w, b, lw, lb, out_scale=gamma, dtype=dtype))
 
 
 class Attention(nn.Module):
@@ -87,17 +99,11 @@ class Attention(nn.Module):
             raise NotImplementedError(f"head_dim {self.dim}/{self.num_heads} unsupported; the fused attention kernel "
                                       f"handles head_dim in {_SUPPORTED_HEAD_DIMS}")
 
-    def _qkv_pack(self, ln=None) -> _ops.PackedLinear:
-        w, b = self.qkv.weight, self.qkv.bias
-        if ln is None:
-            return _ops.cached_pack(self, "qkv", (w, b), lambda: _ops.pack_linear(w, b))
-        return _ops.cached_pack(self, "qkv_ln", (w, b, ln[0], ln[1]), lambda: _ops.pack_linear(w, b, ln[0], ln[1]))
+    def _qkv_pack(self, dtype, ln=None) -> _ops.PackedLinear:
+        return _pack(self, "qkv", dtype, self.qkv.weight, self.qkv.bias, ln=ln)
 
-    def _proj_pack(self, gamma=None) -> _ops.PackedLinear:
-        w, b = self.proj.weight, self.proj.bias
-        if gamma is None:
-            return _ops.cached_pack(self, "proj", (w, b), lambda: _ops.pack_linear(w, b))
-        return _ops.cached_pack(self, "proj_ls", (w, b, gamma), lambda: _ops.pack_linear(w, b, out_scale=gamma))
+    def _proj_pack(self, dtype, gamma=None) -> _ops.PackedLinear:
+        return _pack(self, "proj", dtype, self.proj.weight, self.proj.bias, gamma=gamma)
 
     def _core(self, qkv2d: torch.Tensor, o2d: torch.Tensor, B: int, N: int) -> None:
         _ops.attention(qkv2d, o2d, B, N, self.num_heads, self.head_dim, self.scale)
@@ -109,13 +115,14 @@ class Attention(nn.Module):
         B, N, C = x.shape
         with torch.cuda.device(x.device):
             xb, M = _as_rows(x, C)
-            qkv = torch.empty((M, 3 * C), dtype=torch.bfloat16, device=x.device)
-            _ops.gemm(xb, self._qkv_pack(), qkv, _ops.EPI_BIAS, M)
-            o = _act_buffer(M, C, x.device)
+            dt = xb.dtype
+            qkv = torch.empty((M, 3 * C), dtype=dt, device=x.device)
+            _ops.gemm(xb, self._qkv_pack(dt), qkv, _ops.EPI_BIAS, M)
+            o = _act_buffer(M, C, x.device, dt)
             self._core(qkv, o, B, N)
-            y = torch.empty((M, _ops.round_up(C, 8)), dtype=torch.bfloat16, device=x.device)
-            _ops.gemm(o, self._proj_pack(), y, _ops.EPI_BIAS, M)
-            return _ops.like_input(y[:, :C].reshape(B, N, C), x)
+            y = torch.empty((M, _ops.round_up(C, 8)), dtype=dt, device=x.device)
+            _ops.gemm(o, self._proj_pack(dt), y, _ops.EPI_BIAS, M)
+            return y[:, :C].reshape(B, N, C)
 
 
 class MLP(nn.Module):
@@ -141,17 +148,11 @@ class MLP(nn.Module):
         self.linear_layer2 = self.linear_layer(self.hidden_features, self.out_features, bias=self.bias[1])
 
     # ---- HIP path --------------------------------------------------------------------------------
-    def _fc1_pack(self, ln=None) -> _ops.PackedLinear:
-        w, b = self.linear_layer1.weight, self.linear_layer1.bias
-        if ln is None:
-            return _ops.cached_pack(self, "fc1", (w, b), lambda: _ops.pack_linear(w, b))
-        return _ops.cached_pack(self, "fc1_ln", (w, b, ln[0], ln[1]), lambda: _ops.pack_linear(w, b, ln[0], ln[1]))
+    def _fc1_pack(self, dtype, ln=None) -> _ops.PackedLinear:
+        return _pack(self, "fc1", dtype, self.linear_layer1.weight, self.linear_layer1.bias, ln=ln)
 
-    def _fc2_pack(self, gamma=None) -> _ops.PackedLinear:
-        w, b = self.linear_layer2.weight, self.linear_layer2.bias
-        if gamma is None:
-            return _ops.cached_pack(self, "fc2", (w, b), lambda: _ops.pack_linear(w, b))
-        return _ops.cached_pack(self, "fc2_ls", (w, b, gamma), lambda: _ops.pack_linear(w, b, out_scale=gamma))
+    def _fc2_pack(self, dtype, gamma=None) -> _ops.PackedLinear:
+        return _pack(self, "fc2", dtype, self.linear_layer2.weight, self.linear_layer2.bias, gamma=gamma)
 
     def _check(self):
         if self.use_conv:
@@ -165,12 +166,13 @@ class MLP(nn.Module):
         C = self.in_features
         with torch.cuda.device(x.device):
             xb, M = _as_rows(x, C)
-            p1, p2 = self._fc1_pack(), self._fc2_pack()
-            h = _act_buffer(M, self.hidden_features, x.device, zero_pad_from=p1.npad)
+            dt = xb.dtype
+            p1, p2 = self._fc1_pack(dt), self._fc2_pack(dt)
+            h = _act_buffer(M, self.hidden_features, x.device, dt, zero_pad_from=p1.npad)
             _ops.gemm(xb, p1, h, _ops.EPI_BIAS_GELU, M)
-            y = torch.empty((M, p2.npad), dtype=torch.bfloat16, device=x.device)
+            y = torch.empty((M, p2.npad), dtype=dt, device=x.device)
             _ops.gemm(h, p2, y, _ops.EPI_BIAS, M)
-            return _ops.like_input(y[:, :self.out_features].reshape(*x.shape[:-1], self.out_features), x)
+            return y[:, :self.out_features].reshape(*x.shape[:-1], self.out_features)
 
 
 Mlp = MLP  # timm spelling
@@ -192,14 +194,15 @@ class LayerScale(nn.Module):
         with torch.cuda.device(x.device):
             M = x.numel() // D
             g = _ops.f32vec(self.gamma)
-            if self.inplace and x.dtype == torch.bfloat16 and x.is_contiguous():
+            _ops.compute_dtype(x)
+            if self.inplace and x.is_contiguous():
                 x2 = x.view(M, D)
                 _ops.scale_channels(x2, x2, M, D, g)
                 return x
-            xb = _ops.to_bf16(x.reshape(M, D))
+            xb = x.reshape(M, D).contiguous()
             out = torch.empty_like(xb)
             _ops.scale_channels(xb, out, M, D, g)
-            y = _ops.like_input(out.reshape(x.shape), x)
+            y = out.reshape(x.shape)
             if self.inplace:
                 x.copy_(y)
                 return x
@@ -211,9 +214,10 @@ class Block(nn.Module):
 
     Attention is built with the reference's defaults (no qkv bias, proj bias, no qk-norm, models.py:190-194) and
     the MLP with biases on both layers and ``hidden = int(dim * mlp_ratio)`` (models.py:198-205).
-    On the HIP path a block is seven launches: LN statistics, LN-folded qkv GEMM, fused attention, proj GEMM with
+    On the bf16 path a block is seven launches: LN statistics, LN-folded qkv GEMM, fused attention, proj GEMM with
     bias + LayerScale + residual, LN statistics, LN-folded fc1 GEMM with GELU, fc2 GEMM with bias + LayerScale +
-    residual.
+    residual.  The fp32 path has the same seven with a full LayerNorm in place of the statistics pass (the fp32
+    GEMM does not fold it).
     """
 
     def __init__(self, dim: int, num_heads: int, mlp_ratio: float, norm_layer: Type[nn.Module] = nn.LayerNorm,
@@ -230,38 +234,50 @@ class Block(nn.Module):
 
     # ---- HIP path --------------------------------------------------------------------------------
     def _run(self, x2d: torch.Tensor, B: int, N: int, ws: dict) -> None:
-        """In place on the residual stream x2d ([B*N, ld] bf16); ``ws`` holds the reusable work buffers."""
+        """In place on the residual stream x2d ([B*N, ld], bf16 or fp32); ``ws`` holds the reusable work buffers."""
         attn, mlp = self.attn, self.mlp
         attn._check()
         mlp._check()
-        D, M = self.dim, B * N
+        D, M, dt = self.dim, B * N, x2d.dtype
         ln1 = layernorm_params(self.norm1, "Block.norm1")
         ln2 = layernorm_params(self.norm2, "Block.norm2")
-        # attention branch
-        pk = attn._qkv_pack(ln1)
-        if ln1 is not None:
-            _ops.ln_stats(x2d, M, D, ln1[2], ws["stats"])
-            _ops.gemm(x2d, pk, ws["qkv"], _ops.EPI_LN, M, stats=ws["stats"])
-        else:
-            _ops.gemm(x2d, pk, ws["qkv"], _ops.EPI_BIAS, M)
-        attn._core(ws["qkv"], ws["o"], B, N)
-        _ops.gemm(ws["o"], attn._proj_pack(self.ls1.gamma), x2d, _ops.EPI_RESIDUAL, M, resid=x2d)
-        # MLP branch
-        pk = mlp._fc1_pack(ln2)
-        if ln2 is not None:
-            _ops.ln_stats(x2d, M, D, ln2[2], ws["stats"])
-            _ops.gemm(x2d, pk, ws["h"], _ops.EPI_LN_GELU, M, stats=ws["stats"])
-        else:
-            _ops.gemm(x2d, pk, ws["h"], _ops.EPI_BIAS_GELU, M)
-        _ops.gemm(ws["h"], mlp._fc2_pack(self.ls2.gamma), x2d, _ops.EPI_RESIDUAL, M, resid=x2d)
+        f32 = dt == torch.float32
 
-    def _workspace(self, M: int, device) -> dict:
+        def normed(ln):   # fp32 path: explicit LayerNorm into the work buffer
+            _ops.layernorm(x2d, ws["xn"], M, D, _ops.f32vec(ln[0]), _ops.f32vec(ln[1]), ln[2])
+            return ws["xn"]
+
+        # attention branch
+        if ln1 is None:
+            _ops.gemm(x2d, attn._qkv_pack(dt), ws["qkv"], _ops.EPI_BIAS, M)
+        elif f32:
+            _ops.gemm(normed(ln1), attn._qkv_pack(dt), ws["qkv"], _ops.EPI_BIAS, M)
+        else:
+            _ops.ln_stats(x2d, M, D, ln1[2], ws["stats"])
+            _ops.gemm(x2d, attn._qkv_pack(dt, ln1), ws["qkv"], _ops.EPI_LN, M, stats=ws["stats"])
+        attn._core(ws["qkv"], ws["o"], B, N)
+        _ops.gemm(ws["o"], attn._proj_pack(dt, self.ls1.gamma), x2d, _ops.EPI_RESIDUAL, M, resid=x2d)
+        # MLP branch
+        if ln2 is None:
+            _ops.gemm(x2d, mlp._fc1_pack(dt), ws["h"], _ops.EPI_BIAS_GELU, M)
+        elif f32:
+            _ops.gemm(normed(ln2), mlp._fc1_pack(dt), ws["h"], _ops.EPI_BIAS_GELU, M)
+        else:
+            _ops.ln_stats(x2d, M, D, ln2[2], ws["stats"])
+            _ops.gemm(x2d, mlp._fc1_pack(dt, ln2), ws["h"], _ops.EPI_LN_GELU, M, stats=ws["stats"])
+        _ops.gemm(ws["h"], mlp._fc2_pack(dt, self.ls2.gamma), x2d, _ops.EPI_RESIDUAL, M, resid=x2d)
+
+    def _workspace(self, M: int, device, dtype) -> dict:
         D = self.dim
         hid_npad = _ops.round_up(self.mlp.hidden_features, 8)
-        return dict(stats=torch.empty((M, 2), dtype=torch.float32, device=device),
-                    qkv=torch.empty((M, 3 * D), dtype=torch.bfloat16, device=device),
-                    o=_act_buffer(M, D, device),
-                    h=_act_buffer(M, self.mlp.hidden_features, device, zero_pad_from=hid_npad))
+        ws = dict(qkv=torch.empty((M, 3 * D), dtype=dtype, device=device),
+                  o=_act_buffer(M, D, device, dtype),
+                  h=_act_buffer(M, self.mlp.hidden_features, device, dtype, zero_pad_from=hid_npad))
+        if dtype == torch.float32:
+            ws["xn"] = _act_buffer(M, D, device, dtype)
+        else:
+            ws["stats"] = torch.empty((M, 2), dtype=torch.float32, device=device)
+        return ws
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         """(B, N, D) -> (B, N, D)."""
@@ -273,8 +289,8 @@ class Block(nn.Module):
             xb, M = _as_rows(x, D)
             if xb.data_ptr() == x.data_ptr():
                 xb = xb.clone()  # the block updates its residual stream in place; never the caller's tensor
-            self._run(xb, B, N, self._workspace(M, x.device))
-            return _ops.like_input(xb[:, :D].reshape(B, N, D), x)
+            self._run(xb, B, N, self._workspace(M, x.device, xb.dtype))
+            return xb[:, :D].reshape(B, N, D)
 
 
 class VisionTransformer(nn.Module):
@@ -353,7 +369,7 @@ class VisionTransformer(nn.Module):
 
     # ---- HIP path --------------------------------------------------------------------------------
     def _features2d(self, x: torch.Tensor):
-        """forward_features on the residual-stream buffer: returns (x2d [B*N, ld] bf16, B, N, D)."""
+        """forward_features on the residual-stream buffer: returns (x2d [B*N, ld] in x's dtype, B, N, D)."""
         pe = self.patch_embed
         if not isinstance(pe, PatchEmbed) or not pe.flatten:
             raise NotImplementedError("the HIP path needs this package's PatchEmbed with flatten=True as embed_layer")
@@ -365,7 +381,7 @@ class VisionTransformer(nn.Module):
         N = Np + (1 if has_cls else 0)
         ld = _ops.round_up(D, _ops.k_multiple())
         alloc = torch.zeros if ld != D else torch.empty
-        x2d = alloc((B * N, ld), dtype=torch.bfloat16, device=x.device)
+        x2d = alloc((B * N, ld), dtype=_ops.compute_dtype(x), device=x.device)
         pe._tokens_into(x, x2d, cls_slot=has_cls)
         en = layernorm_params(pe.norm_layer, "PatchEmbed.norm_layer")
         npre = layernorm_params(self.norm_pre, "VisionTransformer.norm_pre")
@@ -384,16 +400,15 @@ class VisionTransformer(nn.Module):
             if not isinstance(blk, Block):
                 raise NotImplementedError(f"block_fn {type(blk).__name__} has no HIP forward")
             if ws is None:
-                ws = blk._workspace(B * N, x.device)
+                ws = blk._workspace(B * N, x.device, x2d.dtype)
             blk._run(x2d, B, N, ws)
         return x2d, B, N, D
 
     def _final_norm(self, x2d: torch.Tensor, B: int, N: int, D: int, like: torch.Tensor) -> torch.Tensor:
         ln = layernorm_params(self.norm_final, "VisionTransformer.norm_final")
         if ln is None:
-            return _ops.like_input(x2d[:, :D].reshape(B, N, D), like)
-        out_dtype = torch.float32 if like.dtype == torch.float32 else torch.bfloat16
-        out = torch.empty((B * N, D), dtype=out_dtype, device=x2d.device)
+            return x2d[:, :D].reshape(B, N, D)
+        out = torch.empty((B * N, D), dtype=x2d.dtype, device=x2d.device)
         _ops.layernorm(x2d, out, B * N, D, _ops.f32vec(ln[0]), _ops.f32vec(ln[1]), ln[2])
         return out.reshape(B, N, D)
 
@@ -402,7 +417,7 @@ class VisionTransformer(nn.Module):
         _ops.require_cuda(x, "VisionTransformer.forward_features")
         with torch.cuda.device(x.device):
             x2d, B, N, D = self._features2d(x)
-            return _ops.like_input(x2d[:, :D].reshape(B, N, D), x)
+            return x2d[:, :D].reshape(B, N, D)
 
     def forward_heads(self, x: torch.Tensor) -> torch.Tensor:
         """Tokens (B, N, D) -> blocks in order -> ``norm_final`` (models.py:408-411)."""
@@ -417,7 +432,7 @@ class VisionTransformer(nn.Module):
                 if not isinstance(blk, Block):
                     raise NotImplementedError(f"block_fn {type(blk).__name__} has no HIP forward")
                 if ws is None:
-                    ws = blk._workspace(M, x.device)
+                    ws = blk._workspace(M, x.device, xb.dtype)
                 blk._run(xb, B, N, ws)
             return self._final_norm(xb, B, N, D, x)
 

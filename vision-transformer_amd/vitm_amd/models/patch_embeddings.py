@@ -55,12 +55,13 @@ class PatchEmbed(nn.Module):
         return image_size, grid_size, grid_size[0] * grid_size[1]
 
     # ---- HIP path --------------------------------------------------------------------------------
-    def _packed_projection(self) -> _ops.PackedLinear:
+    def _packed_projection(self, dtype) -> _ops.PackedLinear:
         w, b = self.projection.weight, self.projection.bias
-        return _ops.cached_pack(self, "projection", (w, b), lambda: _ops.pack_linear(w, b))
+        slot = "projection_f32" if dtype == torch.float32 else "projection_bf16"
+        return _ops.cached_pack(self, slot, (w, b), lambda: _ops.pack_linear(w, b, dtype=dtype))
 
     def _tokens_into(self, x: torch.Tensor, tokens2d: torch.Tensor, cls_slot: bool) -> None:
-        """Write the projected patch tokens of image batch ``x`` into ``tokens2d`` (rows (b, n), bf16)."""
+        """Write the projected patch tokens of image batch ``x`` into ``tokens2d`` (rows (b, n), in x's dtype)."""
         B, C, H, W = x.shape
         assert self.image_size[0] == H, "Input tensor's height does not match the model"
         assert self.image_size[1] == W, "Input tensor's width does not match the model"
@@ -68,7 +69,7 @@ class PatchEmbed(nn.Module):
             raise RuntimeError(f"expected {self.projection.in_channels} input channels, got {C}")
         if x.dtype not in (torch.float32, torch.bfloat16):
             raise TypeError(f"unsupported image dtype {x.dtype} (bf16 or fp32)")
-        _ops.patch_embed(x.contiguous(), self._packed_projection(), tokens2d, self.patch_size,
+        _ops.patch_embed(x.contiguous(), self._packed_projection(tokens2d.dtype), tokens2d, self.patch_size,
                          self.projection.out_channels, cls_slot)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
@@ -80,7 +81,7 @@ class PatchEmbed(nn.Module):
         D, Np = self.projection.out_channels, self.num_patches
         with torch.cuda.device(x.device):
             ld = _ops.round_up(D, 8)
-            tok = torch.empty((B * Np, ld), dtype=torch.bfloat16, device=x.device)
+            tok = torch.empty((B * Np, ld), dtype=_ops.compute_dtype(x), device=x.device)
             self._tokens_into(x, tok, cls_slot=False)
             if self.flatten:
                 ln = layernorm_params(self.norm_layer, "PatchEmbed.norm_layer")
@@ -88,8 +89,7 @@ class PatchEmbed(nn.Module):
                     out = torch.empty_like(tok)
                     _ops.layernorm(tok, out, B * Np, D, _ops.f32vec(ln[0]), _ops.f32vec(ln[1]), ln[2])
                     tok = out
-                y = tok[:, :D].reshape(B, Np, D)
-                return _ops.like_input(y, x)
+                return tok[:, :D].reshape(B, Np, D)
             # flatten=False: the tokens viewed back as NCHW (a layout view, no arithmetic)
             y = tok[:, :D].reshape(B, self.grid_size[0], self.grid_size[1], D).permute(0, 3, 1, 2)
             if self.output_fmt != "NCHW":
@@ -102,4 +102,4 @@ class PatchEmbed(nn.Module):
                 out = torch.empty_like(y2)
                 _ops.layernorm(y2, out, y2.shape[0], D, _ops.f32vec(ln[0]), _ops.f32vec(ln[1]), ln[2])
                 y = out.reshape(y.shape)
-            return _ops.like_input(y.contiguous(), x)
+            return y.contiguous()
