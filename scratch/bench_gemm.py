@@ -34,6 +34,10 @@ def run(name, N, K, epi, iters=30):
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / iters
     print(f"{name:10s} M={M} N={N:5d} K={K:5d} epi={epi}: {ms*1e3:8.1f} us  {2.0*M*N*K/ms/1e9:8.1f} TFLOP/s", flush=True)
+ONLY = os.environ.get("ONLY")
+_run = run
+def run(name, *a, **k):
+    if ONLY is None or name in ONLY.split(","): _run(name, *a, **k)
 run("qkv", 2304, 768, ops.EPI_LN)
 run("proj", 768, 768, ops.EPI_RESIDUAL)
 run("fc1", 3072, 768, ops.EPI_LN_GELU)

@@ -55,9 +55,11 @@ def test_gemm_bias(ops, M, N, K):
 
 @pytest.mark.parametrize("epi", ["bias", "ln", "ln_gelu", "resid", "bias_f32"])
 @pytest.mark.parametrize("M,N,K", [(8200, 2304, 768), (11111, 768, 3072), (9000, 1152, 384), (33000, 3072, 768),
-                                   (16400, 520, 64)])
+                                   (16400, 520, 64), (50432, 768, 768), (50432, 3072, 768), (40000, 1024, 128),
+                                   (66000, 512, 256)])
 def test_gemm_big_tile_kernel(ops, M, N, K, epi):
-    """Shapes large enough to be routed to the 256x256 ping-pong kernel (ragged M and N tails included)."""
+    """Shapes large enough to be routed to the 256x256 ping-pong kernel (ragged M and N tails included); the
+    last four leave a partly filled last round whose tiles are shared 3, 4, 2 and 4 ways between workgroups."""
     A = _bf(_rand(M, K, seed=40) * 1.3 + 0.2)
     W, b = _rand(N, K, seed=41, scale=K ** -0.5), _rand(N, seed=42, scale=0.2)
     F = torch.nn.functional

@@ -18,6 +18,7 @@ struct GemmArgs {
   const bf16_t* resid;
   int64_t ldr;
   int M, N, K, tilesM, tilesN, row_group;
+  int ncu, share, S;   // big-tile kernel: persistent workgroups, leftover tiles shared (0/1) by S workgroups each
   // im2col source (patch embedding)
   const void* img;
   int C, H, Wd, ph, pw, gw, npatch, kreal, vec;
