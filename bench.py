@@ -120,6 +120,7 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="images per GPU per step")
     ap.add_argument("--config", default="vit_b16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph", action="store_true", help="replay the forward from a HIP graph (same kernels, one host call)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -150,13 +151,17 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    fwd = model
+    if args.graph:
+        from vitm_amd import GraphedForward
+        fwd = GraphedForward(model, x)
     with torch.no_grad():
         for _ in range(args.warmup):
-            model(x)
+            fwd(x)
         barrier()
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            out = model(x)
+            out = fwd(x)
         barrier()
         elapsed = time.perf_counter() - t0
     assert torch.isfinite(out.float()).all()
@@ -183,6 +188,7 @@ def main():
                                    f"{shp['num_classes']} classes; classification forward (VITC)",
                        "batch_per_gpu": args.batch, "global_batch": args.batch * world,
                        "parallelism": f"batch-sharded replicas x{world}, no collective",
+                       "launch": "hip-graph replay" if args.graph else "eager (one host call per kernel)",
                        "gflop_per_image": round(gflop_img, 3)},
             "roofline": {"bound": "mfma", "achieved": round(fc1_tflops, 1), "peak": PEAK_BF16_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(fc1_tflops / PEAK_BF16_TFLOPS, 4),

@@ -17,7 +17,10 @@ def run(name, N, K, epi, iters=30):
         pk = ops.pack_linear(W, b, torch.ones(K, device=DEV), torch.zeros(K, device=DEV))
         stats = ops.ln_stats(A, M, K, 1e-5)
         out = torch.empty((M, N), dtype=torch.bfloat16, device=DEV)
-        f = lambda: ops.gemm(A, pk, out, epi, M, stats=stats)
+        if os.environ.get("FUSE", "0") == "1":
+            f = lambda: ops.gemm_ln(A, pk, out, epi, M, K, 1e-5)
+        else:
+            f = lambda: ops.gemm(A, pk, out, epi, M, stats=stats)
     elif epi == ops.EPI_RESIDUAL:
         pk = ops.pack_linear(W, b, out_scale=torch.ones(N, device=DEV))
         x = torch.randn(M, N, device=DEV).to(torch.bfloat16)

@@ -170,3 +170,21 @@ def test_batch_independence_and_determinism():
         halves = torch.cat([model(x[:3]), model(x[3:])])
     assert torch.equal(full, again)
     assert torch.equal(full, halves)
+
+
+@pytest.mark.parametrize("name,batch", [("vit_tiny_cifar", 16), ("vit_s16", 4)])
+def test_graph_replay_is_bit_identical(name, batch):
+    """The forward captured into a HIP graph replays the same kernels on the same buffers."""
+    from vitm_amd import GraphedForward
+    model, sd, cfg = build(name, seed=2)
+    x1 = torch.from_numpy(W.make_input(cfg, batch, 3)).cuda().to(torch.bfloat16)
+    x2 = torch.from_numpy(W.make_input(cfg, batch, 4)).cuda().to(torch.bfloat16)
+    with torch.no_grad():
+        e1, e2 = model(x1).clone(), model(x2).clone()
+        g = GraphedForward(model, x1)
+        r1 = g(x1).clone()
+        r2 = g(x2).clone()
+        r1b = g(x1).clone()
+    assert torch.equal(r1, e1) and torch.equal(r2, e2) and torch.equal(r1b, e1)
+    with pytest.raises(RuntimeError):
+        g(x1[:1])
