@@ -143,6 +143,16 @@ int vitm_attention(const void* qkv, int64_t ldqkv, void* out, int64_t ldo, int B
                    int head_dim, float scale, vitm_stream_t stream);
 
 /*
+ * Per-head LayerNorm of q and k, in place on the packed qkv activation (bf16 or fp32): for every row and
+ * head, q[h*hd : (h+1)*hd] and k[h*hd : (h+1)*hd] are normalised over head_dim with (q_w, q_b, q_eps) /
+ * (k_w, k_b, k_eps); v is untouched.  Run it between the qkv GEMM and vitm_attention.
+ * Replaces q_norm / k_norm of Attention(qk_norm=True) (models.py:54-55,82).
+ */
+int vitm_qk_norm(void* qkv, int dtype, int64_t ldqkv, int M, int H, int head_dim, const float* q_w,
+                 const float* q_b, float q_eps, const float* k_w, const float* k_b, float k_eps,
+                 vitm_stream_t stream);
+
+/*
  * Same attention with fp32 qkv and out and fp32 arithmetic throughout (leading dimensions multiples
  * of 4).  Replaces models.py:79-93 for fp32 tensors.
  */

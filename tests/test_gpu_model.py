@@ -188,3 +188,27 @@ def test_graph_replay_is_bit_identical(name, batch):
     assert torch.equal(r1, e1) and torch.equal(r2, e2) and torch.equal(r1b, e1)
     with pytest.raises(RuntimeError):
         g(x1[:1])
+
+
+@pytest.mark.parametrize("name", ["attn_qknorm_hd64", "attn_qknorm_hd96", "attn_qkvbias_hd32"])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_attention_variants_match_reference_golden(name, dtype):
+    """Attention(qkv_bias=True / qk_norm=True) against fixtures captured from the imported reference: fp32 to
+    1e-4 relative, bf16 no further from the fp32 reference than 1.5x the reference's own bf16 forward."""
+    from vitm_amd.models.models import Attention
+    g = np.load(os.path.join(GOLD, f"{name}.npz"))
+    sd = {k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd.")}
+    x = torch.from_numpy(g["x"])
+    m = Attention(x.shape[-1], num_heads=int(g["heads"]), qkv_bias=bool(g["qkv_bias"]), qk_norm=bool(g["qk_norm"])).eval()
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda().to(dtype)
+    with torch.no_grad():
+        y = m(x.cuda().to(dtype))
+    assert y.dtype == dtype
+    ref = torch.from_numpy(g["y"])
+    err = (y.float().cpu() - ref).abs().max().item()
+    if dtype == torch.float32:
+        assert err <= 1e-4 * ref.abs().max().item(), err
+    else:
+        yard = (torch.from_numpy(g["y_ref_bf16"]) - ref).abs().max().item()
+        assert err <= 1.5 * yard, f"{name}: err {err:.4g} vs the reference's own bf16 forward {yard:.4g}"

@@ -74,3 +74,13 @@ def test_flops_formula_matches_survey_numbers():
     for name, gf in (("vit_s16", 9.197), ("vit_b16", 35.128), ("vit_b16_384", 110.969), ("vit_l16", 123.109)):
         f = O.flops_per_image(W.shapes(W.CONFIGS[name])) / 1e9
         assert abs(f - gf) / gf < 2e-3, (name, f)
+
+
+@pytest.mark.parametrize("name", ["attn_qknorm_hd64", "attn_qknorm_hd96", "attn_qkvbias_hd32"])
+def test_oracle_attention_variants_match_reference(name):
+    """Attention(qkv_bias / qk_norm) fixtures captured from the imported reference (models.py:32-35,54-55,82)."""
+    g = np.load(os.path.join(GOLD, f"{name}.npz"))
+    sd = {k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd.")}
+    y = O.attention(torch.from_numpy(g["x"]), sd, int(g["heads"]), "")
+    ref = torch.from_numpy(g["y"])
+    assert (y - ref).abs().max().item() <= TOL * max(1.0, ref.abs().max().item())

@@ -191,6 +191,70 @@ __global__ __launch_bounds__(256) void scale_channels_kernel(const T* __restrict
   }
 }
 
+// Per-head LayerNorm of q and k (Attention(qk_norm=True)), in place on the packed qkv activation.  A slot of SL
+// lanes (the next power of two >= head_dim / 8) owns one head vector; reductions stay inside the slot.
+template <typename T, int HD>
+__global__ __launch_bounds__(256) void qk_norm_kernel(T* __restrict__ qkv, int64_t ld, int64_t nvec, int H,
+                                                      const float* __restrict__ qw, const float* __restrict__ qb,
+                                                      float qeps, const float* __restrict__ kw,
+                                                      const float* __restrict__ kb, float keps) {
+  constexpr int LPV = HD / 8;
+  constexpr int SL = LPV <= 4 ? 4 : (LPV <= 8 ? 8 : 16);
+  const int64_t vec = ((int64_t)blockIdx.x * 256 + threadIdx.x) / SL;
+  const int sub = threadIdx.x % SL;
+  const bool live = vec < nvec && sub < LPV;
+  const int64_t m = live ? vec / (2 * H) : 0;
+  const int j = live ? (int)(vec - m * 2 * H) : 0;
+  const bool isk = j >= H;
+  const int h = isk ? j - H : j;
+  T* ptr = qkv + m * ld + (int64_t)(isk ? H * HD : 0) + h * HD + sub * 8;
+  float v[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = 0.f;
+  if (live) load8<T>(ptr, v);
+  float s = 0.f;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) s += v[e];
+#pragma unroll
+  for (int o = 1; o < SL; o <<= 1) s += __shfl_xor(s, o, 64);
+  const float mean = s / (float)HD;
+  float q = 0.f;
+  if (live) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) q = fmaf(v[e] - mean, v[e] - mean, q);
+  }
+#pragma unroll
+  for (int o = 1; o < SL; o <<= 1) q += __shfl_xor(q, o, 64);
+  const float rstd = 1.0f / sqrtf(q / (float)HD + (isk ? keps : qeps));
+  if (live) {
+    float wv[8], bv[8];
+    load8<float>((isk ? kw : qw) + sub * 8, wv);
+    load8<float>((isk ? kb : qb) + sub * 8, bv);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = fmaf((v[e] - mean) * rstd, wv[e], bv[e]);
+    store8(ptr, v);
+  }
+}
+
+template <typename T>
+int launch_qk_norm(void* qkv, int64_t ld, int M, int H, int hd, const float* qw, const float* qb, float qeps,
+                   const float* kw, const float* kb, float keps, hipStream_t st) {
+  const int64_t nvec = (int64_t)M * 2 * H;
+  const int lpv = hd / 8, sl = lpv <= 4 ? 4 : (lpv <= 8 ? 8 : 16);
+  const dim3 grid((unsigned)((nvec * sl + 255) / 256)), blk(256);
+  switch (hd) {
+    case 32: hipLaunchKernelGGL((qk_norm_kernel<T, 32>), grid, blk, 0, st, (T*)qkv, ld, nvec, H, qw, qb, qeps, kw, kb, keps); break;
+    case 64: hipLaunchKernelGGL((qk_norm_kernel<T, 64>), grid, blk, 0, st, (T*)qkv, ld, nvec, H, qw, qb, qeps, kw, kb, keps); break;
+    case 96: hipLaunchKernelGGL((qk_norm_kernel<T, 96>), grid, blk, 0, st, (T*)qkv, ld, nvec, H, qw, qb, qeps, kw, kb, keps); break;
+    case 128: hipLaunchKernelGGL((qk_norm_kernel<T, 128>), grid, blk, 0, st, (T*)qkv, ld, nvec, H, qw, qb, qeps, kw, kb, keps); break;
+    default:
+      vitm_set_error("vitm_qk_norm: head_dim=%d unsupported (32, 64, 96, 128)", hd);
+      return VITM_EUNSUPPORTED;
+  }
+  VITM_CHECK_LAUNCH("vitm_qk_norm");
+  return VITM_OK;
+}
+
 __device__ __forceinline__ float block_sum_256(float v, float* sh) {
   v = wave_sum(v);
   __syncthreads();
@@ -324,6 +388,20 @@ extern "C" int vitm_embed_finalize(void* x, int x_dtype, int64_t ldx, int B, int
   }
   VITM_CHECK_LAUNCH("vitm_embed_finalize");
   return VITM_OK;
+}
+
+extern "C" int vitm_qk_norm(void* qkv, int dtype, int64_t ldqkv, int M, int H, int head_dim, const float* q_w,
+                            const float* q_b, float q_eps, const float* k_w, const float* k_b, float k_eps,
+                            vitm_stream_t stream) {
+  VITM_REQUIRE(qkv && q_w && q_b && k_w && k_b, "vitm_qk_norm: null pointer");
+  VITM_REQUIRE(dtype == VITM_BF16 || dtype == VITM_F32, "vitm_qk_norm: bad dtype %d", dtype);
+  VITM_REQUIRE(M > 0 && H > 0 && head_dim > 0, "vitm_qk_norm: M, H, head_dim must be positive");
+  VITM_REQUIRE(ldqkv >= 3 * (int64_t)H * head_dim && ldqkv % 8 == 0 && al16(qkv), "vitm_qk_norm: ldqkv/alignment");
+  VITM_REQUIRE(al16(q_w) && al16(q_b) && al16(k_w) && al16(k_b), "vitm_qk_norm: vectors must be 16-byte aligned");
+  VITM_REQUIRE((int64_t)M * 2 * H * 16 / 256 < (1ll << 31), "vitm_qk_norm: too many rows for one launch");
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == VITM_BF16) return launch_qk_norm<bf16_t>(qkv, ldqkv, M, H, head_dim, q_w, q_b, q_eps, k_w, k_b, k_eps, st);
+  return launch_qk_norm<float>(qkv, ldqkv, M, H, head_dim, q_w, q_b, q_eps, k_w, k_b, k_eps, st);
 }
 
 extern "C" int vitm_scale_channels(const void* x, int64_t ldx, void* out, int64_t ldo, int dtype, int M, int D,

@@ -183,6 +183,11 @@ def attention(qkv: torch.Tensor, out: torch.Tensor, B: int, N: int, H: int, hd: 
                                           _stream()), "vitm_attention")
 
 
+def qk_norm(qkv: torch.Tensor, M: int, H: int, hd: int, qw, qb, qeps: float, kw, kb, keps: float) -> None:
+    _lib.check(_lib.load().vitm_qk_norm(_p(qkv), _dt(qkv), qkv.stride(0), M, H, hd, _p(qw), _p(qb), float(qeps),
+                                        _p(kw), _p(kb), float(keps), _stream()), "vitm_qk_norm")
+
+
 def layernorm(x: torch.Tensor, out: torch.Tensor, M: int, D: int, w: torch.Tensor, b: torch.Tensor, eps: float) -> None:
     _lib.check(_lib.load().vitm_layernorm(_p(x), _dt(x), x.stride(0), _p(out), _dt(out), out.stride(0), M, D, _p(w), _p(b),
                                           float(eps), _stream()), "vitm_layernorm")

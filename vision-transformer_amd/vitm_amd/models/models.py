@@ -14,7 +14,9 @@ Deliberate differences from the reference's HEAD, all supersets of what can run 
   * ``embed_dim`` is forwarded to ``embed_layer`` (models.py:291-295 drops it, so only 768 works there);
   * ``norm_layer=None`` leaves ``norm_pre`` an Identity and lets the blocks use their LayerNorm default
     (the reference passes None into Block, models.py:317, and fails);
-  * ``fused_attention=True`` runs the same fused kernel (the reference branch is a stub, models.py:84-85).
+  * ``fused_attention=True`` runs the same fused kernel (the reference branch is a stub, models.py:84-85);
+  * ``qk_norm=True`` / ``qkv_bias=True`` are supported (per-head LayerNorm kernel before the attention kernel;
+    the bias rides in the qkv GEMM epilogue).
 """
 from __future__ import annotations
 
@@ -93,8 +95,6 @@ class Attention(nn.Module):
 
     # ---- HIP path --------------------------------------------------------------------------------
     def _check(self):
-        if self.qk_norm:
-            raise NotImplementedError("Attention(qk_norm=True) is not on the HIP path yet")
         if self.head_dim * self.num_heads != self.dim or self.head_dim not in _SUPPORTED_HEAD_DIMS:
             raise NotImplementedError(f"head_dim {self.dim}/{self.num_heads} unsupported; the fused attention kernel "
                                       f"handles head_dim in {_SUPPORTED_HEAD_DIMS}")
@@ -106,6 +106,16 @@ class Attention(nn.Module):
         return _pack(self, "proj", dtype, self.proj.weight, self.proj.bias, gamma=gamma)
 
     def _core(self, qkv2d: torch.Tensor, o2d: torch.Tensor, B: int, N: int) -> None:
+        """qkv [B*N, 3C] -> attention output [B*N, C]; with qk_norm the per-head LayerNorm of q and k
+        (models.py:82) runs in place on qkv first."""
+        qn = layernorm_params(self.q_norm, "Attention.q_norm")
+        kn = layernorm_params(self.k_norm, "Attention.k_norm")
+        if (qn is None) != (kn is None):
+            raise NotImplementedError("q_norm and k_norm must both be LayerNorm or both Identity")
+        if qn is not None:
+            f = _ops.f32vec
+            _ops.qk_norm(qkv2d, B * N, self.num_heads, self.head_dim, f(qn[0]), f(qn[1]), qn[2],
+                         f(kn[0]), f(kn[1]), kn[2])
         _ops.attention(qkv2d, o2d, B, N, self.num_heads, self.head_dim, self.scale)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
