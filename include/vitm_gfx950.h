@@ -171,6 +171,12 @@ int vitm_layernorm(const void* x, int x_dtype, int64_t ldx, void* out, int out_d
 int vitm_scale_channels(const void* x, int64_t ldx, void* out, int64_t ldo, int dtype, int M, int D,
                         const float* gamma, vitm_stream_t stream);
 
+/*
+ * out[m,n] = gelu_erf(x[m,n]), x and out in `dtype`: nn.GELU() stand-alone, as the ViT-22B block's MLP applies
+ * it to an already projected hidden activation (parallel_block.py:121-124).
+ */
+int vitm_gelu(const void* x, int64_t ldx, void* out, int64_t ldo, int dtype, int M, int D, vitm_stream_t stream);
+
 /* dst (bf16) <- src (f32), n elements; used to bring fp32 images/activations onto the bf16 path. */
 int vitm_cast_f32_to_bf16(const float* src, void* dst, int64_t n, vitm_stream_t stream);
 /* dst (f32) <- src (bf16), n elements. */

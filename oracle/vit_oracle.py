@@ -143,6 +143,33 @@ def attention(x: torch.Tensor, sd, num_heads: int, prefix: str, dtype=torch.floa
     return o
 
 
+def parallel_block(x: torch.Tensor, sd, num_heads: int, prefix: str = "", dtype=torch.float32) -> torch.Tensor:
+    """ParallelBlock.forward (parallel_block.py:193-221): LayerNorm -> one projection to [q | k | v | mlp hidden]
+    -> attention with per-head LayerNorm of q and k (scores scaled AFTER q.k^T, parallel_block.py:88-91) in parallel
+    with GELU + out_proj (:121-124) -> concat -> fused_proj_2 -> LayerScale -> + x."""
+    B, N, C = x.shape
+    hd = C // num_heads
+    nx = layer_norm(x, _t(sd, prefix + "norm.weight", dtype), _t(sd, prefix + "norm.bias", dtype))
+    f1 = nx @ _t(sd, prefix + "fused_proj_1.weight", dtype).t() + _t(sd, prefix + "fused_proj_1.bias", dtype)
+    qkv, hid = f1[..., :3 * C], f1[..., 3 * C:]
+    qkv = qkv.reshape(B, N, 3, num_heads, hd).permute(2, 0, 3, 1, 4)
+    q, k, v = qkv[0], qkv[1], qkv[2]
+    q = layer_norm(q, _t(sd, prefix + "attn.q_norm.weight", dtype), _t(sd, prefix + "attn.q_norm.bias", dtype))
+    k = layer_norm(k, _t(sd, prefix + "attn.k_norm.weight", dtype), _t(sd, prefix + "attn.k_norm.bias", dtype))
+    s = (q @ k.transpose(-2, -1)) * (hd ** -0.5)
+    s = s - s.amax(dim=-1, keepdim=True)
+    p = torch.exp(s)
+    p = p / p.sum(dim=-1, keepdim=True)
+    a = (p @ v).permute(0, 2, 1, 3).reshape(B, N, C)
+    a = a @ _t(sd, prefix + "attn.proj.weight", dtype).t() + _t(sd, prefix + "attn.proj.bias", dtype)
+    m = gelu_erf(hid) @ _t(sd, prefix + "mlp.out_proj.weight", dtype).t()
+    mb = _t(sd, prefix + "mlp.out_proj.bias", dtype)
+    if mb is not None:
+        m = m + mb
+    f2 = torch.cat((a, m), dim=-1) @ _t(sd, prefix + "fused_proj_2.weight", dtype).t() + _t(sd, prefix + "fused_proj_2.bias", dtype)
+    return x + f2 * _t(sd, prefix + "layer_scale.gamma", dtype)
+
+
 def mlp(x: torch.Tensor, sd, prefix: str, dtype=torch.float32) -> torch.Tensor:
     """MLP.forward (models.py:126-130): linear_layer1 -> GELU(erf) -> linear_layer2."""
     h = x @ _t(sd, prefix + "linear_layer1.weight", dtype).t()

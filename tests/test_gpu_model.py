@@ -212,3 +212,76 @@ def test_attention_variants_match_reference_golden(name, dtype):
     else:
         yard = (torch.from_numpy(g["y_ref_bf16"]) - ref).abs().max().item()
         assert err <= 1.5 * yard, f"{name}: err {err:.4g} vs the reference's own bf16 forward {yard:.4g}"
+
+
+@pytest.mark.parametrize("name", ["pblock_d128", "pblock_d192"])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_parallel_block_matches_reference_golden(name, dtype):
+    """The ViT-22B style block against fixtures captured from the imported reference (parallel_block.py:193-221)."""
+    from vitm_amd.models import ParallelBlock
+    g = np.load(os.path.join(GOLD, f"{name}.npz"))
+    sd = {k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd.")}
+    x = torch.from_numpy(g["x"])
+    m = ParallelBlock(x.shape[-1], int(g["heads"]), mlp_ratio=float(g["mlp_ratio"]), mlp_bias=bool(g["mlp_bias"])).eval()
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda().to(dtype)
+    with torch.no_grad():
+        xin = x.cuda().to(dtype)
+        keep = xin.clone()
+        y = m(xin)
+    assert torch.equal(xin, keep), "the block must not modify its input"
+    ref = torch.from_numpy(g["y"])
+    err = (y.float().cpu() - ref).abs().max().item()
+    if dtype == torch.float32:
+        assert err <= 1e-4 * ref.abs().max().item(), err
+    else:
+        yard = (torch.from_numpy(g["y_ref_bf16"]) - ref).abs().max().item()
+        assert err <= 1.5 * yard, f"{name}: err {err:.4g} vs the reference's own bf16 forward {yard:.4g}"
+
+
+def test_parallel_block_submodules_and_vit():
+    """Stand-alone forwards of the block's attention and MLP, and a VisionTransformer(parallel_block=True) + head,
+    against the CPU oracle in fp32 (1e-4 relative)."""
+    from oracle import vit_oracle as O
+    from vitm_amd.models import ParallelBlock, VisionTransformer, VITC
+    torch.manual_seed(0)
+    F = torch.nn.functional
+    blk = ParallelBlock(128, 2, mlp_ratio=1.0, mlp_bias=True).cuda().eval()
+    with torch.no_grad():
+        for p in blk.parameters():
+            p.normal_(0, 0.2)
+        qkv = torch.randn(2, 40, 384, device="cuda")
+        sd = {k: v.cpu() for k, v in blk.state_dict().items()}
+        # attention sub-module
+        q, k, v = qkv.cpu().double().reshape(2, 40, 3, 2, 64).permute(2, 0, 3, 1, 4)
+        ln = lambda t, w, b: F.layer_norm(t, (64,), w.double(), b.double(), 1e-5)
+        q, k = ln(q, sd["attn.q_norm.weight"], sd["attn.q_norm.bias"]), ln(k, sd["attn.k_norm.weight"], sd["attn.k_norm.bias"])
+        a = ((q @ k.transpose(-2, -1)) * 64 ** -0.5).softmax(-1) @ v
+        ref = a.permute(0, 2, 1, 3).flatten(-2) @ sd["attn.proj.weight"].double().t() + sd["attn.proj.bias"].double()
+        assert rel_err(blk.attn(qkv).cpu(), ref) < 1e-4
+        h = torch.randn(2, 40, 128, device="cuda")
+        ref = F.gelu(h.cpu().double()) @ sd["mlp.out_proj.weight"].double().t() + sd["mlp.out_proj.bias"].double()
+        assert rel_err(blk.mlp(h).cpu(), ref) < 1e-4
+        # whole model
+        LN = nn.LayerNorm
+        vt = VisionTransformer(32, patch_size=8, num_classes=7, num_heads=2, mlp_ratio=0.7, depth=2, embed_dim=128,
+                               norm_layer=LN, final_norm_layer=LN, parallel_block=True)
+        model = VITC(vt).eval()
+        for n, p in model.named_parameters():
+            if n.endswith("gamma") or "norm" in n:
+                p.copy_(1.0 + 0.1 * torch.randn_like(p))
+            elif n.endswith("bias"):
+                p.normal_(0, 0.1)
+        msd = {k: v.clone() for k, v in model.state_dict().items()}
+        x = torch.randn(3, 3, 32, 32)
+        cfg = dict(image_size=32, patch_size=(8, 8), num_heads=2)
+        f = O.forward_features(x, msd, cfg, "vit_model.")
+        for i in range(2):
+            f = O.parallel_block(f, msd, 2, f"vit_model.blocks.{i}.")
+        emb = O.layer_norm(f, msd["vit_model.norm_final.weight"], msd["vit_model.norm_final.bias"])
+        ref_logits = emb[:, 0] @ msd["head.weight"].t() + msd["head.bias"]
+        model = model.cuda()
+        got = model(x.cuda())
+        assert rel_err(got.cpu(), ref_logits) < 1e-4
+        gb = model.to(torch.bfloat16)(x.cuda().to(torch.bfloat16))
+        assert (gb.float().cpu() - ref_logits).abs().max().item() <= logit_tol(ref_logits) * 1.5

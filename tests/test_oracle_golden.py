@@ -84,3 +84,13 @@ def test_oracle_attention_variants_match_reference(name):
     y = O.attention(torch.from_numpy(g["x"]), sd, int(g["heads"]), "")
     ref = torch.from_numpy(g["y"])
     assert (y - ref).abs().max().item() <= TOL * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("name", ["pblock_d128", "pblock_d192"])
+def test_oracle_parallel_block_matches_reference(name):
+    """ParallelBlock fixtures captured from the imported reference (parallel_block.py:193-221)."""
+    g = np.load(os.path.join(GOLD, f"{name}.npz"))
+    sd = {k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd.")}
+    y = O.parallel_block(torch.from_numpy(g["x"]), sd, int(g["heads"]))
+    ref = torch.from_numpy(g["y"])
+    assert (y - ref).abs().max().item() <= TOL * max(1.0, ref.abs().max().item())

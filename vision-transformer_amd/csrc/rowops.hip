@@ -255,6 +255,23 @@ int launch_qk_norm(void* qkv, int64_t ld, int M, int H, int hd, const float* qw,
   return VITM_OK;
 }
 
+// out = gelu_erf(x) elementwise (stand-alone activation): erf to 1.5e-7 in both dtypes
+template <typename T>
+__global__ __launch_bounds__(256) void gelu_kernel(const T* __restrict__ x, int64_t ldx, T* __restrict__ out, int64_t ldo,
+                                                   int M, int D) {
+  const int cpr = D / 8;
+  const int64_t total = (int64_t)M * cpr;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t m = i / cpr;
+    const int c = (int)(i - m * cpr) * 8;
+    float v[8];
+    load8<T>(x + m * ldx + c, v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = gelu_erf_accurate(v[e]);
+    store8(out + m * ldo + c, v);
+  }
+}
+
 __device__ __forceinline__ float block_sum_256(float v, float* sh) {
   v = wave_sum(v);
   __syncthreads();
@@ -402,6 +419,21 @@ extern "C" int vitm_qk_norm(void* qkv, int dtype, int64_t ldqkv, int M, int H, i
   hipStream_t st = (hipStream_t)stream;
   if (dtype == VITM_BF16) return launch_qk_norm<bf16_t>(qkv, ldqkv, M, H, head_dim, q_w, q_b, q_eps, k_w, k_b, k_eps, st);
   return launch_qk_norm<float>(qkv, ldqkv, M, H, head_dim, q_w, q_b, q_eps, k_w, k_b, k_eps, st);
+}
+
+extern "C" int vitm_gelu(const void* x, int64_t ldx, void* out, int64_t ldo, int dtype, int M, int D, vitm_stream_t stream) {
+  VITM_REQUIRE(x && out, "vitm_gelu: null pointer");
+  VITM_REQUIRE(dtype == VITM_BF16 || dtype == VITM_F32, "vitm_gelu: bad dtype %d", dtype);
+  VITM_REQUIRE(M > 0 && D > 0 && D % 8 == 0 && ldx >= D && ldo >= D && ldx % 8 == 0 && ldo % 8 == 0, "vitm_gelu: D/ld must be multiples of 8");
+  VITM_REQUIRE(al16(x) && al16(out), "vitm_gelu: pointers must be 16-byte aligned");
+  const dim3 grid(stream_grid((int64_t)M * (D / 8)));
+  if (dtype == VITM_BF16) {
+    hipLaunchKernelGGL(gelu_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, (bf16_t*)out, ldo, M, D);
+  } else {
+    hipLaunchKernelGGL(gelu_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)x, ldx, (float*)out, ldo, M, D);
+  }
+  VITM_CHECK_LAUNCH("vitm_gelu");
+  return VITM_OK;
 }
 
 extern "C" int vitm_scale_channels(const void* x, int64_t ldx, void* out, int64_t ldo, int dtype, int M, int D,

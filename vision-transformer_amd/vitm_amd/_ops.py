@@ -199,6 +199,11 @@ def scale_channels(x: torch.Tensor, out: torch.Tensor, M: int, D: int, gamma: to
                                                _stream()), "vitm_scale_channels")
 
 
+def gelu(x: torch.Tensor, out: torch.Tensor, M: int, D: int) -> None:
+    assert x.dtype == out.dtype
+    _lib.check(_lib.load().vitm_gelu(_p(x), x.stride(0), _p(out), out.stride(0), _dt(x), M, D, _stream()), "vitm_gelu")
+
+
 def to_bf16(x: torch.Tensor) -> torch.Tensor:
     """A contiguous bf16 copy of a contiguous fp32/bf16 CUDA tensor (cast kernel, not torch)."""
     x = x.contiguous()

@@ -15,6 +15,8 @@ Deliberate differences from the reference's HEAD, all supersets of what can run 
   * ``norm_layer=None`` leaves ``norm_pre`` an Identity and lets the blocks use their LayerNorm default
     (the reference passes None into Block, models.py:317, and fails);
   * ``fused_attention=True`` runs the same fused kernel (the reference branch is a stub, models.py:84-85);
+  * ``parallel_block=True`` builds ``ParallelBlock`` with its own signature (the reference passes Block's
+    positional arguments, models.py:311-321, and fails);
   * ``qk_norm=True`` / ``qkv_bias=True`` are supported (per-head LayerNorm kernel before the attention kernel;
     the bias rides in the qkv GEMM epilogue).
 """
@@ -307,8 +309,8 @@ class VisionTransformer(nn.Module):
     """timm-style ViT encoder: patch embedding, class token, ``norm_pre`` (applied BEFORE the positional
     embedding is added, models.py:359-360), ``depth`` blocks, ``norm_final``; returns all tokens (B, N, D).
 
-    Constructor arguments are those of models.py:261-281.  ``parallel_block=True`` (the ViT-22B block) and
-    the DTensor helpers ``parallelize_blocks`` / ``spawn_parallel`` are outside this forward path.
+    Constructor arguments are those of models.py:261-281 (``parallel_block=True`` selects the ViT-22B block of
+    parallel_block.py).  The DTensor helpers ``parallelize_blocks`` / ``spawn_parallel`` are outside this forward path.
     """
 
     def __init__(self, image_size: Union[int, Tuple[int, int]], patch_size: int, num_classes: int, num_heads: int,
@@ -319,8 +321,6 @@ class VisionTransformer(nn.Module):
                  act_layer: Optional[nn.Module] = nn.GELU, parallel_block: bool = False,
                  shard_along_dims: tuple = None):
         super().__init__()
-        if parallel_block:
-            raise NotImplementedError("parallel_block=True (ViT-22B ParallelBlock) is outside the MI355X forward path")
         self.embed_dim = embed_dim
         self.num_classes = num_classes
         self.image_size = image_size
@@ -347,8 +347,16 @@ class VisionTransformer(nn.Module):
 
         self.norm_pre = norm_layer(embed_dim) if norm_layer else nn.Identity()
         block_norm = norm_layer if norm_layer else nn.LayerNorm
-        self.blocks = nn.ModuleList([
-            block_fn(embed_dim, num_heads, mlp_ratio, block_norm, act_layer, vit=True) for _ in range(depth)])
+        if parallel_block:
+            # the reference passes Block's positional arguments to ParallelBlock (models.py:311-321), which puts the
+            # norm layer in the activation slot and fails; this is the call its signature (parallel_block.py:172-180)
+            # asks for
+            from .parallel_block import ParallelBlock
+            self.blocks = nn.ModuleList([
+                ParallelBlock(embed_dim, num_heads, mlp_ratio, act_layer=act_layer, vit=True) for _ in range(depth)])
+        else:
+            self.blocks = nn.ModuleList([
+                block_fn(embed_dim, num_heads, mlp_ratio, block_norm, act_layer, vit=True) for _ in range(depth)])
         self.norm_final = final_norm_layer(embed_dim) if final_norm_layer else nn.Identity()
         self.feature_info = [dict(module=f"block_{i}", num_chs=embed_dim) for i in range(depth)]
         self.parallel_block = parallel_block
@@ -407,7 +415,7 @@ class VisionTransformer(nn.Module):
         x2d, B, N, D = self._features2d(x)
         ws = None
         for blk in self.blocks:
-            if not isinstance(blk, Block):
+            if not hasattr(blk, "_run"):
                 raise NotImplementedError(f"block_fn {type(blk).__name__} has no HIP forward")
             if ws is None:
                 ws = blk._workspace(B * N, x.device, x2d.dtype)
@@ -439,7 +447,7 @@ class VisionTransformer(nn.Module):
                 xb = xb.clone()
             ws = None
             for blk in self.blocks:
-                if not isinstance(blk, Block):
+                if not hasattr(blk, "_run"):
                     raise NotImplementedError(f"block_fn {type(blk).__name__} has no HIP forward")
                 if ws is None:
                     ws = blk._workspace(M, x.device, xb.dtype)
