@@ -182,11 +182,7 @@ int launch_attn(const void* qkv, int64_t ldq, void* out, int64_t ldo, int B, int
   const int kchunk = npad < KCHUNK_MAX ? npad : KCHUNK_MAX;
   const int smem = 2 * kchunk * (HD * 2 + 16);
   auto kfn = attn_kernel<HD>;
-  if (hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess) {
-    vitm_set_error("vitm_attention: cannot reserve %d bytes of LDS", smem);
-    (void)hipGetLastError();
-    return VITM_ELAUNCH;
-  }
+  VITM_LDS_OPTIN(kfn, 2 * KCHUNK_MAX * (HD * 2 + 16), "vitm_attention");   // once, for the largest chunk
   const int nqb = (N + QB - 1) / QB;
   const int nqg = (nqb + WAVES - 1) / WAVES;
   dim3 grid((unsigned)((int64_t)nqg * B * H));

@@ -131,11 +131,7 @@ int launch_attn_f32(const float* qkv, int64_t ldq, float* out, int64_t ldo, int 
   if (npad < kchunk) kchunk = npad;
   const int smem = 2 * kchunk * HD * 4;
   auto kfn = attn_f32_kernel<HD>;
-  if (hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess) {
-    vitm_set_error("vitm_attention_f32: cannot reserve %d bytes of LDS", smem);
-    (void)hipGetLastError();
-    return VITM_ELAUNCH;
-  }
+  VITM_LDS_OPTIN(kfn, 2 * ((8192 / HD) / SUB * SUB) * HD * 4, "vitm_attention_f32");   // once, for the largest chunk
   const int nqb = (N + QPB - 1) / QPB;
   hipLaunchKernelGGL(kfn, dim3((unsigned)((int64_t)nqb * B * H)), dim3(256), smem, st, qkv, ldq, out, ldo, N, H,
                      scale * 1.4426950408889634f, kchunk, nqb);

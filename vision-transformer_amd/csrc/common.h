@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
+#include <atomic>
 
 #include "../../include/vitm_gfx950.h"
 
@@ -119,6 +120,26 @@ void vitm_set_error(const char* fmt, ...);
       return VITM_EINVAL;                  \
     }                                      \
   } while (0)
+
+// One-time (per kernel instantiation and device) opt-in to more than 64 KiB of dynamic LDS; cheap afterwards.
+#define VITM_LDS_OPTIN(kfn, bytes, what)                                                            \
+  do {                                                                                              \
+    static std::atomic<unsigned long long> done__{0};                                               \
+    int dev__ = 0;                                                                                  \
+    (void)hipGetDevice(&dev__);                                                                     \
+    const unsigned long long bit__ = 1ull << (dev__ & 63);                                          \
+    if (!(done__.load(std::memory_order_relaxed) & bit__)) {                                        \
+      if (hipFuncSetAttribute((const void*)(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (bytes)) != hipSuccess) { \
+        vitm_set_error("%s: cannot reserve %d bytes of LDS", what, (int)(bytes));                   \
+        (void)hipGetLastError();                                                                    \
+        return VITM_ELAUNCH;                                                                        \
+      }                                                                                             \
+      done__.fetch_or(bit__, std::memory_order_relaxed);                                            \
+    }                                                                                               \
+  } while (0)
+
+// compute units of the calling thread's current device (cached per device)
+int vitm_cu_count();
 
 #define VITM_CHECK_LAUNCH(name)                                                   \
   do {                                                                            \

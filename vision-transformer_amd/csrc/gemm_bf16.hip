@@ -214,11 +214,7 @@ template <int EPI, int AMODE, int OUT_F32>
 int launch(const GemmArgs& a, hipStream_t st) {
   auto kfn = gemm_kernel<EPI, AMODE, OUT_F32>;
   // > 64 KiB of dynamic LDS needs the opt-in; it is per function and device, cheap and idempotent.
-  if (hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES) != hipSuccess) {
-    vitm_set_error("vitm_gemm: cannot reserve %d bytes of LDS", SMEM_BYTES);
-    (void)hipGetLastError();
-    return VITM_ELAUNCH;
-  }
+  VITM_LDS_OPTIN(kfn, SMEM_BYTES, "vitm_gemm");
   const int tilesM = (a.M + BM - 1) / BM;
   dim3 grid((unsigned)(tilesM * a.tilesN));
   hipLaunchKernelGGL(kfn, grid, dim3(NTHREADS), SMEM_BYTES, st, a);

@@ -229,11 +229,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_f32_kernel(const Args p) {
 template <int EPI, int AMODE>
 int launch(const Args& a, hipStream_t st) {
   auto kfn = gemm_f32_kernel<EPI, AMODE>;
-  if (hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES) != hipSuccess) {
-    vitm_set_error("vitm_gemm_f32: cannot reserve %d bytes of LDS", SMEM_BYTES);
-    (void)hipGetLastError();
-    return VITM_ELAUNCH;
-  }
+  VITM_LDS_OPTIN(kfn, SMEM_BYTES, "vitm_gemm_f32");
   const int tilesM = (a.M + BM - 1) / BM;
   hipLaunchKernelGGL(kfn, dim3((unsigned)(tilesM * a.tilesN)), dim3(NTHREADS), SMEM_BYTES, st, a);
   VITM_CHECK_LAUNCH("vitm_gemm_f32");

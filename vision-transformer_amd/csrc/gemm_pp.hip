@@ -475,11 +475,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_pp_kernel(const GemmArgs p) {
 template <int EPI, int NBLK, bool SLICE>
 int launch_one(const GemmArgs& b, int grid, hipStream_t st) {
   auto kfn = gemm_pp_kernel<EPI, NBLK, SLICE>;
-  if (hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess) {
-    vitm_set_error("vitm_gemm: cannot reserve %d bytes of LDS", SMEM);
-    (void)hipGetLastError();
-    return VITM_ELAUNCH;
-  }
+  VITM_LDS_OPTIN(kfn, SMEM, "vitm_gemm");
   hipLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3(NT), SMEM, st, b);
   VITM_CHECK_LAUNCH("vitm_gemm (256x256 tile)");
   return VITM_OK;
@@ -490,8 +486,7 @@ int launch(const GemmArgs& a, hipStream_t st) {
   GemmArgs b = a;
   b.tilesN = (a.N + BN - 1) / BN;
   b.tilesM = (a.M + BM - 1) / BM;
-  int dev = 0, ncu = 256;
-  if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+  const int ncu = vitm_cu_count();
   const int64_t tiles = (int64_t)b.tilesM * b.tilesN;
   const int grid = (int)(tiles < ncu ? tiles : ncu);   // one persistent workgroup per CU
   b.ncu = grid;
