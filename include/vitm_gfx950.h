@@ -107,6 +107,23 @@ int vitm_patch_embed(const void* img, int img_dtype, int B, int C, int H, int W,
                      int64_t ldo, int D, int cls_slot, vitm_stream_t stream);
 
 /*
+ * 1 when vitm_gemm (bf16 output, row_group 0) runs this shape on the persistent 256x256-tile kernel, 0 when on
+ * the 128x128 one.  Lets a caller decide between vitm_patch_embed (im2col fused into the 128x128 kernel's tile
+ * loader: right for small batches) and vitm_im2col + vitm_gemm (one extra pass over the patches, then the
+ * faster kernel: right for large ones).
+ */
+int vitm_gemm_uses_big_tile(int M, int N, int K);
+
+/*
+ * Patch matrix for vitm_gemm: out[(b, cls_slot + patch), k] = img[b, c, py*ph+ky, px*pw+kx], k = (c, ky, kx) in
+ * Conv2d.weight.reshape(D, -1) order, bf16, K padded with zeros to kpad; with cls_slot = 1 row 0 of every image
+ * is a zero row (the GEMM then leaves bias there; vitm_embed_finalize overwrites it with the class token).
+ * img is NCHW bf16 or fp32.  First half of PatchEmbed.forward's Conv2d (patch_embeddings.py:115) at large batch.
+ */
+int vitm_im2col(const void* img, int img_dtype, int B, int C, int H, int W, int ph, int pw, void* out,
+                int64_t ldo, int kpad, int cls_slot, vitm_stream_t stream);
+
+/*
  * Full-precision GEMM: as vitm_gemm with A, Wp, out and resid all fp32 and the fp32 matrix
  * instruction.  K a multiple of vitm_gemm_k_multiple(), N and the leading dimensions multiples of 4.
  * Epilogues: VITM_EPI_BIAS, VITM_EPI_BIAS_GELU (erf to 1.5e-7), VITM_EPI_RESIDUAL; LayerNorm is not

@@ -225,6 +225,32 @@ def test_patch_embed(ops, img, p, D, B, dtype):
         _close(got, ref_in, what="patch embed")
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("img,p,D,B", [(224, 16, 768, 160), (64, 8, 256, 520), (60, 6, 256, 400)])
+def test_patch_embed_large_batch_route(ops, img, p, D, B, dtype):
+    """Batches large enough for the patch-matrix pass + big-tile GEMM route (vector and element-wise gathers)."""
+    from oracle import vit_oracle as O
+    from vitm_amd import _lib
+    x = (_rand(B, 3, img, img, seed=60)).to(dtype)
+    w = _rand(D, 3, p, p, seed=61, scale=(3 * p * p) ** -0.5)
+    b = _rand(D, seed=62, scale=0.1)
+    pk = ops.pack_linear(w, b)
+    Np = (img // p) ** 2
+    assert _lib.load().vitm_gemm_uses_big_tile(B * Np, pk.npad, pk.kpad) == 1
+    for cls_slot in (False, True):
+        rows = B * (Np + int(cls_slot))
+        tok = torch.full((rows, D), 7.0, dtype=torch.bfloat16, device=DEV)
+        ops.patch_embed(x, pk, tok, (p, p), D, cls_slot)
+        got = tok.view(B, Np + int(cls_slot), D)
+        if cls_slot:
+            _close(got[:, 0], b.expand(B, D), what="class-token slot holds the bias until embed_finalize")
+            got = got[:, 1:]
+        for lo in range(0, B, 64):   # chunked reference
+            cols = O.im2col(x[lo:lo + 64].to(torch.bfloat16).float().cpu(), (p, p)).to(DEV)
+            ref = cols @ _bf(w).float().reshape(D, -1).t() + b
+            _close(got[lo:lo + 64], ref, what="patch embed (large batch)")
+
+
 def test_embed_finalize_and_layernorm(ops):
     B, N, D = 3, 65, 192
     tok = _bf(_rand(B * N, D, seed=25))

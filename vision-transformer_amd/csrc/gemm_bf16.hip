@@ -250,6 +250,7 @@ inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 }  // namespace
 
 extern "C" int vitm_gemm_k_multiple(void) { return BK; }
+extern "C" int vitm_gemm_uses_big_tile(int M, int N, int K) { return vitm_gemm_pp_wanted(M, N, K) ? 1 : 0; }
 
 extern "C" int vitm_gemm(const void* A, int64_t lda, const void* Wp, int64_t ldw, void* out, int64_t ldo,
                          int out_dtype, int M, int N, int K, int epilogue, const float* stats,

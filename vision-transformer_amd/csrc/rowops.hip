@@ -255,6 +255,47 @@ int launch_qk_norm(void* qkv, int64_t ld, int M, int H, int hd, const float* qw,
   return VITM_OK;
 }
 
+// Patch matrix of an NCHW image batch (bf16 out): row (b, cls + patch) holds the patch's (c, ky, kx) values in the
+// order of Conv2d.weight.reshape(D, -1); the class-token row (when cls = 1) and the K padding are zero.
+template <typename TI>
+__global__ __launch_bounds__(256) void im2col_kernel(const TI* __restrict__ img, bf16_t* __restrict__ out, int64_t ldo,
+                                                     int64_t rows, int C, int H, int W, int ph, int pw, int gw,
+                                                     int npatch, int kreal, int kpad, int cls, int vec) {
+  const int cpr = kpad / 8;
+  const int64_t total = rows * cpr;
+  const int pp = ph * pw;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = i / cpr;
+    const int k0 = (int)(i - row * cpr) * 8;
+    const int64_t b = row / (npatch + cls);
+    const int n = (int)(row - b * (npatch + cls)) - cls;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = 0.f;
+    if (n >= 0 && k0 < kreal) {
+      const int py = n / gw, px = n - py * gw;
+      const int64_t base = ((int64_t)b * C * H + (int64_t)py * ph) * W + (int64_t)px * pw;
+      if (vec && k0 + 8 <= kreal) {
+        const int c = k0 / pp, kr = k0 - c * pp;
+        const int ky = kr / pw, kx = kr - ky * pw;
+        load8<TI>(img + base + ((int64_t)c * H + ky) * W + kx, v);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int k = k0 + e;
+          if (k < kreal) {
+            const int c = k / pp, kr = k - c * pp;
+            const int ky = kr / pw, kx = kr - ky * pw;
+            const TI t = img[base + ((int64_t)c * H + ky) * W + kx];
+            if (sizeof(TI) == 2) v[e] = bf2f(*(const bf16_t*)&t); else v[e] = *(const float*)&t;
+          }
+        }
+      }
+    }
+    store8(out + row * ldo + k0, v);
+  }
+}
+
 // out = gelu_erf(x) elementwise (stand-alone activation): erf to 1.5e-7 in both dtypes
 template <typename T>
 __global__ __launch_bounds__(256) void gelu_kernel(const T* __restrict__ x, int64_t ldx, T* __restrict__ out, int64_t ldo,
@@ -419,6 +460,30 @@ extern "C" int vitm_qk_norm(void* qkv, int dtype, int64_t ldqkv, int M, int H, i
   hipStream_t st = (hipStream_t)stream;
   if (dtype == VITM_BF16) return launch_qk_norm<bf16_t>(qkv, ldqkv, M, H, head_dim, q_w, q_b, q_eps, k_w, k_b, k_eps, st);
   return launch_qk_norm<float>(qkv, ldqkv, M, H, head_dim, q_w, q_b, q_eps, k_w, k_b, k_eps, st);
+}
+
+extern "C" int vitm_im2col(const void* img, int img_dtype, int B, int C, int H, int W, int ph, int pw, void* out,
+                           int64_t ldo, int kpad, int cls_slot, vitm_stream_t stream) {
+  VITM_REQUIRE(img && out, "vitm_im2col: null pointer");
+  VITM_REQUIRE(img_dtype == VITM_BF16 || img_dtype == VITM_F32, "vitm_im2col: bad img_dtype %d", img_dtype);
+  VITM_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && ph > 0 && pw > 0, "vitm_im2col: bad shape");
+  const int gh = H / ph, gw = W / pw;
+  VITM_REQUIRE(gh > 0 && gw > 0, "vitm_im2col: patch larger than the image");
+  const int kreal = C * ph * pw;
+  VITM_REQUIRE(kpad >= kreal && kpad % 8 == 0 && ldo >= kpad && ldo % 8 == 0 && al16(out), "vitm_im2col: kpad/ldo/alignment");
+  const int vec = (pw % 8 == 0) && (W % 8 == 0) && (((uintptr_t)img & 31) == 0);
+  const int64_t rows = (int64_t)B * (gh * gw + (cls_slot ? 1 : 0));
+  const dim3 grid(stream_grid(rows * (kpad / 8)));
+  hipStream_t st = (hipStream_t)stream;
+  if (img_dtype == VITM_F32) {
+    hipLaunchKernelGGL(im2col_kernel<float>, grid, dim3(256), 0, st, (const float*)img, (bf16_t*)out, ldo, rows, C, H, W, ph, pw,
+                       gw, gh * gw, kreal, kpad, cls_slot ? 1 : 0, vec);
+  } else {
+    hipLaunchKernelGGL(im2col_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)img, (bf16_t*)out, ldo, rows, C, H, W, ph,
+                       pw, gw, gh * gw, kreal, kpad, cls_slot ? 1 : 0, vec);
+  }
+  VITM_CHECK_LAUNCH("vitm_im2col");
+  return VITM_OK;
 }
 
 extern "C" int vitm_gelu(const void* x, int64_t ldx, void* out, int64_t ldo, int dtype, int M, int D, vitm_stream_t stream) {

@@ -52,6 +52,9 @@ SIGNATURES = {
     "vitm_layernorm": (c_int, [c_void_p, c_int, c_int64, c_void_p, c_int, c_int64, c_int, c_int, c_void_p, c_void_p,
                                c_float, c_void_p]),
     "vitm_scale_channels": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "vitm_gemm_uses_big_tile": (c_int, [c_int, c_int, c_int]),
+    "vitm_im2col": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int64, c_int, c_int,
+                            c_void_p]),
     "vitm_gelu": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
     "vitm_cast_f32_to_bf16": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "vitm_cast_bf16_to_f32": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),

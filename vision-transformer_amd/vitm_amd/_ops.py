@@ -156,6 +156,17 @@ def gemm(A: torch.Tensor, pk: PackedLinear, out: torch.Tensor, epilogue: int, M:
 
 def patch_embed(img: torch.Tensor, pk: PackedLinear, tokens: torch.Tensor, patch, D: int, cls_slot: bool) -> None:
     B, C, H, W = img.shape
+    if tokens.dtype == torch.bfloat16 and pk.npad == D:
+        # large batch: one pass that writes the patch matrix, then the persistent big-tile GEMM
+        npatch = (H // patch[0]) * (W // patch[1])
+        rows = B * (npatch + (1 if cls_slot else 0))
+        lib = _lib.load()
+        if lib.vitm_gemm_uses_big_tile(rows, pk.npad, pk.kpad):
+            A = torch.empty((rows, pk.kpad), dtype=torch.bfloat16, device=img.device)
+            _lib.check(lib.vitm_im2col(_p(img), _dt(img), B, C, H, W, patch[0], patch[1], _p(A), pk.kpad, pk.kpad,
+                                       1 if cls_slot else 0, _stream()), "vitm_im2col")
+            gemm(A, pk, tokens, EPI_BIAS, rows)
+            return
     if tokens.dtype == torch.float32:
         assert pk.dtype == torch.float32
         _lib.check(_lib.load().vitm_patch_embed_f32(
