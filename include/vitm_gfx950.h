@@ -199,6 +199,71 @@ int vitm_cast_f32_to_bf16(const float* src, void* dst, int64_t n, vitm_stream_t 
 /* dst (f32) <- src (bf16), n elements. */
 int vitm_cast_bf16_to_f32(const void* src, float* dst, int64_t n, vitm_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------------
+ * Training step, fp32 (the reference trains in fp32: vitm/training/train.py:208-241).  The GEMMs of the
+ * backward pass are vitm_gemm_f32 calls on transposed operands; the entry points below are the rest.
+ * ------------------------------------------------------------------------------------------------------ */
+
+/*
+ * vitm_attention_f32 that also writes lse[b, h, n] = log2 of the softmax denominator of query n (scores taken
+ * times scale*log2(e)), the one per-row number the backward pass needs to recompute the probabilities.
+ */
+int vitm_attention_f32_lse(const float* qkv, int64_t ldqkv, float* out, int64_t ldo, float* lse, int B, int N,
+                           int H, int head_dim, float scale, vitm_stream_t stream);
+
+/*
+ * Backward of models.py:88-93: dqkv (B*N, 3*D; [dq | dk | dv], every element written) from qkv, the forward
+ * output o, d_o and lse.  `delta` is a (B*H*N) fp32 scratch array (row sums of d_o * o).
+ */
+int vitm_attention_bwd_f32(const float* qkv, int64_t ldqkv, const float* o, int64_t ldo, const float* d_o,
+                           int64_t lddo, const float* lse, float* dqkv, int64_t lddqkv, float* delta, int B, int N,
+                           int H, int head_dim, float scale, vitm_stream_t stream);
+
+/* dst[n, m] = src[m, n] for m < M, zero for M <= m < m_pad (K padding of the weight-gradient GEMM's operands). */
+int vitm_transpose_f32(const float* src, int64_t lds, float* dst, int64_t ldd, int M, int N, int m_pad,
+                       vitm_stream_t stream);
+
+/*
+ * out[c, d] = sum over the rows m of chunk c (nchunks equal chunks of the M rows) of a[m, d] * (b ? b[m, d] : 1).
+ * Bias gradients (b = NULL), LayerScale gradients (a = d_y, b = branch output), second stage of LayerNorm
+ * parameter gradients.  Call once with nchunks > 1 into a partial array, then once with nchunks = 1 over it.
+ */
+int vitm_colsum_f32(const float* a, int64_t lda, const float* b, int64_t ldb, float* out, int64_t ldo, int M,
+                    int D, int nchunks, vitm_stream_t stream);
+
+/*
+ * LayerNorm backward: dx[m,:] = (dx_add ? dx_add[m,:] : 0) + rstd * (g - mean(g) - xhat * mean(g * xhat)), g = dy * w;
+ * dw_partial / db_partial are (nblocks, D) per-workgroup sums of dy * xhat / dy (reduce them with vitm_colsum_f32).
+ * Backward of nn.LayerNorm (models.py:189,196,310,324).
+ */
+int vitm_layernorm_bwd_f32(const float* x, int64_t ldx, const float* dy, int64_t lddy, const float* w, float eps,
+                           const float* dx_add, int64_t ldadd, float* dx, int64_t lddx, float* dw_partial,
+                           float* db_partial, int nblocks, int M, int D, vitm_stream_t stream);
+
+/* dpre = dh * d/dx gelu_erf(pre): backward of nn.GELU() (models.py:128). */
+int vitm_gelu_bwd_f32(const float* pre, int64_t ldp, const float* dh, int64_t ldh, float* dpre, int64_t ldd, int M,
+                      int D, vitm_stream_t stream);
+
+/*
+ * loss[0] = mean over the batch of softmax cross-entropy(logits[b,:], labels[b]); dlogits (optional) its gradient.
+ * nn.CrossEntropyLoss() with class-index targets (train.py:187,220).
+ */
+int vitm_cross_entropy_f32(const float* logits, int64_t ld, const int64_t* labels, int B, int C, float* loss,
+                           float* dlogits, int64_t lddl, vitm_stream_t stream);
+
+/*
+ * torch.nn.utils.clip_grad_norm_(parameters, max_norm) (train.py:222) on one flat gradient buffer of n floats:
+ * norm_and_coef[0] = L2 norm, [1] = min(1, max_norm / (norm + 1e-6)), grads *= [1].  `scratch` holds
+ * vitm_grad_clip_scratch_floats() floats.
+ */
+int vitm_grad_clip_f32(float* grads, int64_t n, float max_norm, float* scratch, float* norm_and_coef,
+                       vitm_stream_t stream);
+int vitm_grad_clip_scratch_floats(void);
+
+/* One torch.optim.AdamW update (train.py:68-72) of a parameter tensor of n floats; `step` counts from 1. */
+int vitm_adamw_f32(float* p, const float* g, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
+                   float beta2, float eps, float weight_decay, int step, vitm_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

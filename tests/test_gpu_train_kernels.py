@@ -1,0 +1,140 @@
+"""fp32 training kernels on a real MI355X against float64 PyTorch (autograd where a gradient is checked).
+Bar: 1e-4 relative (max|got - ref| / max|ref|), 1e-5 for the element-wise ones."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+F = torch.nn.functional
+
+
+@pytest.fixture(scope="module")
+def T():
+    from vitm_amd import _train_ops
+    return _train_ops
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(DEV)
+
+
+def _rel(got, ref):
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    assert torch.isfinite(got).all()
+    return ((got.double() - ref.double()).abs().max() / ref.double().abs().max().clamp_min(1e-30)).item()
+
+
+@pytest.mark.parametrize("M,N,mp", [(100, 70, 128), (33, 257, 64), (5000, 192, 5056), (64, 64, 64)])
+def test_transpose(T, M, N, mp):
+    src = _rand(M, N + 8, seed=1)[:, :N]
+    dst = T.transpose(src, M, N, mp)
+    assert torch.equal(dst[:, :M], src.t()) and (dst[:, M:] == 0).all()
+
+
+@pytest.mark.parametrize("M,D", [(1, 8), (50, 100), (5000, 768), (197 * 16, 614)])
+def test_colsum(T, M, D):
+    a, b = _rand(M, D, seed=2), _rand(M, D, seed=3)
+    assert _rel(T.colsum(a, M, D), a.double().sum(0)) <= 1e-5
+    assert _rel(T.colsum(a, M, D, b), (a.double() * b.double()).sum(0)) <= 1e-5
+    assert torch.equal(T.colsum(a, M, D, b), T.colsum(a, M, D, b)), "deterministic"
+
+
+@pytest.mark.parametrize("M,D", [(7, 64), (300, 192), (2000, 768), (65, 1024)])
+def test_layernorm_bwd(T, M, D):
+    x = (_rand(M, D, seed=4) * 2 + 0.5).double().requires_grad_(True)
+    w = (1 + 0.2 * _rand(D, seed=5)).double().requires_grad_(True)
+    b = (0.1 * _rand(D, seed=6)).double().requires_grad_(True)
+    dy, add = _rand(M, D, seed=7), _rand(M, D, seed=8)
+    F.layer_norm(x, (D,), w, b, 1e-5).backward(dy.double())
+    dx = torch.empty((M, D), device=DEV)
+    dw, db = torch.empty(D, device=DEV), torch.empty(D, device=DEV)
+    T.layernorm_bwd(x.detach().float(), dy, w.detach().float(), 1e-5, M, D, dx, dx_add=add, dw_out=dw, db_out=db)
+    assert _rel(dx, x.grad + add.double()) <= 1e-4
+    assert _rel(dw, w.grad) <= 1e-4 and _rel(db, b.grad) <= 1e-4
+    T.layernorm_bwd(x.detach().float(), dy, w.detach().float(), 1e-5, M, D, dx)
+    assert _rel(dx, x.grad) <= 1e-4
+
+
+def test_gelu_bwd(T):
+    M, D = 300, 200
+    pre = (_rand(M, D, seed=9) * 2).double().requires_grad_(True)
+    dh = _rand(M, D, seed=10)
+    F.gelu(pre).backward(dh.double())
+    out = torch.empty((M, D), device=DEV)
+    T.gelu_bwd(pre.detach().float(), dh, out, M, D)
+    assert _rel(out, pre.grad) <= 1e-5
+
+
+@pytest.mark.parametrize("B,C", [(4, 10), (64, 10), (256, 1000), (3, 7)])
+def test_cross_entropy(T, B, C):
+    logits = (_rand(B, C, seed=11) * 3).double().requires_grad_(True)
+    labels = torch.randint(0, C, (B,), generator=torch.Generator().manual_seed(12)).to(DEV)
+    ref = F.cross_entropy(logits, labels)
+    ref.backward()
+    loss, dl = T.cross_entropy(logits.detach().float(), labels)
+    assert abs(loss.item() - ref.item()) <= 1e-5 * max(1.0, abs(ref.item()))
+    assert _rel(dl, logits.grad) <= 1e-5
+
+
+def test_grad_clip_matches_torch(T):
+    for scale in (0.01, 5.0):
+        g = _rand(1_234_567, seed=13, scale=scale)
+        ref = g.clone().requires_grad_(False)
+        p = torch.nn.Parameter(torch.zeros_like(ref))
+        p.grad = ref
+        norm = torch.nn.utils.clip_grad_norm_([p], 1.0)
+        nc = T.grad_clip(g, 1.0)
+        assert abs(nc[0].item() - norm.item()) <= 1e-5 * norm.item()
+        assert _rel(g, p.grad) <= 1e-5
+
+
+def test_adamw_matches_torch(T):
+    n = 100_003
+    p0, g1, g2 = _rand(n, seed=14), _rand(n, seed=15, scale=0.1), _rand(n, seed=16, scale=0.1)
+    ref = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.AdamW([ref], lr=1e-3, weight_decay=0.05, betas=(0.9, 0.98))
+    p, m, v = p0.clone(), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    for step, g in enumerate((g1, g2), 1):
+        ref.grad = g.clone()
+        opt.step()
+        T.adamw(p, g, m, v, 1e-3, 0.9, 0.98, 1e-8, 0.05, step)
+        assert _rel(p, ref.detach()) <= 1e-6
+    st = opt.state[ref]
+    assert _rel(m, st["exp_avg"]) <= 1e-6 and _rel(v, st["exp_avg_sq"]) <= 1e-6
+
+
+@pytest.mark.parametrize("M,N,K", [(200, 136, 128), (197 * 3, 768, 192), (65, 10, 192), (1000, 614, 768)])
+def test_linear_backward_from_forward_gemm(T, M, N, K):
+    x = _rand(M, K, seed=17).double().requires_grad_(True)
+    w = (_rand(N, K, seed=18) * K ** -0.5).double().requires_grad_(True)
+    dy = _rand(M, N, seed=19)
+    (x @ w.t()).backward(dy.double())
+    dx = T.linear_dx(dy, w.detach().float(), M)
+    assert _rel(dx[:, :K], x.grad) <= 1e-4
+    dw = T.linear_dw(dy, x.detach().float(), M, N, K)
+    assert _rel(dw, w.grad) <= 1e-4
+
+
+@pytest.mark.parametrize("B,N,H,hd", [(2, 65, 3, 64), (1, 197, 2, 64), (2, 50, 2, 96), (1, 33, 2, 32), (1, 100, 1, 128),
+                                      (1, 300, 1, 64), (2, 1, 2, 64)])
+def test_attention_backward(T, B, N, H, hd):
+    from vitm_amd import _ops
+    D = H * hd
+    qkv = (_rand(B * N, 3 * D, seed=20) * 1.2)
+    d_o = _rand(B * N, D, seed=21)
+    q64 = qkv.double().requires_grad_(True)
+    q, k, v = q64.reshape(B, N, 3, H, hd).permute(2, 0, 3, 1, 4)
+    ref_o = (((q * hd ** -0.5) @ k.transpose(-2, -1)).softmax(-1) @ v).transpose(1, 2).reshape(B * N, D)
+    ref_o.backward(d_o.double())
+    o = torch.empty((B * N, D), device=DEV)
+    lse = torch.empty(B * H * N, device=DEV)
+    T.attention_lse(qkv, o, lse, B, N, H, hd, hd ** -0.5)
+    o2 = torch.empty_like(o)
+    _ops.attention(qkv, o2, B, N, H, hd, hd ** -0.5)
+    assert torch.equal(o, o2), "the lse variant computes the same output"
+    assert _rel(o, ref_o.detach()) <= 1e-4
+    dqkv = torch.full((B * N, 3 * D), float("nan"), device=DEV)
+    T.attention_bwd(qkv, o, d_o, lse, dqkv, B, N, H, hd, hd ** -0.5)
+    for name, sl in (("dq", slice(0, D)), ("dk", slice(D, 2 * D)), ("dv", slice(2 * D, 3 * D))):
+        assert _rel(dqkv[:, sl], q64.grad[:, sl]) <= 1e-4, name

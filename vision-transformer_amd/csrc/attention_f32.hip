@@ -17,7 +17,7 @@ constexpr int SUB = 8;       // keys per online-softmax step
 template <int HD>
 __global__ __launch_bounds__(256) void attn_f32_kernel(const float* __restrict__ qkv, int64_t ldq,
                                                        float* __restrict__ out, int64_t ldo, int N, int H,
-                                                       float sl2e, int kchunk, int nqb) {
+                                                       float sl2e, int kchunk, int nqb, float* __restrict__ lse) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int DP = HD / 4;      // head-dim slice per lane
   constexpr int V4 = DP / 4;      // float4 per slice
@@ -120,12 +120,14 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(const float* __restrict__
 #pragma unroll
     for (int v = 0; v < V4; ++v)
       *(float4*)(op + 4 * v) = make_float4(o[4 * v] * inv, o[4 * v + 1] * inv, o[4 * v + 2] * inv, o[4 * v + 3] * inv);
+    // log2-domain log-sum-exp of the scaled scores, kept for the backward pass: p = exp2(s * scale * log2e - lse)
+    if (lse != nullptr && part == 0) lse[((int64_t)b * H + h) * N + qrow] = m_run + __log2f(l_run);
   }
 }
 
 template <int HD>
 int launch_attn_f32(const float* qkv, int64_t ldq, float* out, int64_t ldo, int B, int N, int H, float scale,
-                    hipStream_t st) {
+                    float* lse, hipStream_t st) {
   int kchunk = (8192 / HD) / SUB * SUB;          // 64 KiB of LDS for K and V together
   const int npad = (N + SUB - 1) / SUB * SUB;
   if (npad < kchunk) kchunk = npad;
@@ -134,15 +136,15 @@ int launch_attn_f32(const float* qkv, int64_t ldq, float* out, int64_t ldo, int 
   VITM_LDS_OPTIN(kfn, 2 * ((8192 / HD) / SUB * SUB) * HD * 4, "vitm_attention_f32");   // once, for the largest chunk
   const int nqb = (N + QPB - 1) / QPB;
   hipLaunchKernelGGL(kfn, dim3((unsigned)((int64_t)nqb * B * H)), dim3(256), smem, st, qkv, ldq, out, ldo, N, H,
-                     scale * 1.4426950408889634f, kchunk, nqb);
+                     scale * 1.4426950408889634f, kchunk, nqb, lse);
   VITM_CHECK_LAUNCH("vitm_attention_f32");
   return VITM_OK;
 }
 
 }  // namespace
 
-extern "C" int vitm_attention_f32(const float* qkv, int64_t ldqkv, float* out, int64_t ldo, int B, int N, int H,
-                                  int head_dim, float scale, vitm_stream_t stream) {
+static int attention_f32_impl(const float* qkv, int64_t ldqkv, float* out, int64_t ldo, int B, int N, int H,
+                              int head_dim, float scale, float* lse, vitm_stream_t stream) {
   VITM_REQUIRE(qkv && out, "vitm_attention_f32: null pointer");
   VITM_REQUIRE(B > 0 && N > 0 && H > 0, "vitm_attention_f32: B, N, H must be positive");
   VITM_REQUIRE((int64_t)B * H * ((N + QPB - 1) / QPB) < (1ll << 31), "vitm_attention_f32: grid too large for one launch");
@@ -153,12 +155,23 @@ extern "C" int vitm_attention_f32(const float* qkv, int64_t ldqkv, float* out, i
   VITM_REQUIRE(scale > 0.f, "vitm_attention_f32: scale must be positive");
   hipStream_t st = (hipStream_t)stream;
   switch (head_dim) {
-    case 32: return launch_attn_f32<32>(qkv, ldqkv, out, ldo, B, N, H, scale, st);
-    case 64: return launch_attn_f32<64>(qkv, ldqkv, out, ldo, B, N, H, scale, st);
-    case 96: return launch_attn_f32<96>(qkv, ldqkv, out, ldo, B, N, H, scale, st);
-    case 128: return launch_attn_f32<128>(qkv, ldqkv, out, ldo, B, N, H, scale, st);
+    case 32: return launch_attn_f32<32>(qkv, ldqkv, out, ldo, B, N, H, scale, lse, st);
+    case 64: return launch_attn_f32<64>(qkv, ldqkv, out, ldo, B, N, H, scale, lse, st);
+    case 96: return launch_attn_f32<96>(qkv, ldqkv, out, ldo, B, N, H, scale, lse, st);
+    case 128: return launch_attn_f32<128>(qkv, ldqkv, out, ldo, B, N, H, scale, lse, st);
     default: break;
   }
   vitm_set_error("vitm_attention_f32: head_dim=%d unsupported (32, 64, 96, 128)", head_dim);
   return VITM_EUNSUPPORTED;
+}
+
+extern "C" int vitm_attention_f32(const float* qkv, int64_t ldqkv, float* out, int64_t ldo, int B, int N, int H,
+                                  int head_dim, float scale, vitm_stream_t stream) {
+  return attention_f32_impl(qkv, ldqkv, out, ldo, B, N, H, head_dim, scale, nullptr, stream);
+}
+
+extern "C" int vitm_attention_f32_lse(const float* qkv, int64_t ldqkv, float* out, int64_t ldo, float* lse, int B, int N,
+                                      int H, int head_dim, float scale, vitm_stream_t stream) {
+  VITM_REQUIRE(lse, "vitm_attention_f32_lse: null lse");
+  return attention_f32_impl(qkv, ldqkv, out, ldo, B, N, H, head_dim, scale, lse, stream);
 }

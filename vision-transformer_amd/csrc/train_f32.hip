@@ -1,0 +1,334 @@
+// fp32 kernels of the training step for gfx950 (the reference trains in fp32, vitm/training/train.py:208-241):
+// the pieces of the backward pass that are not GEMMs, the loss, gradient clipping and the optimizer update.
+//
+//   transpose          dst[n, m] = src[m, n], K padding of the destination zeroed (operands of the weight-gradient GEMM)
+//   colsum             out[c, d] = sum over the rows of chunk c of a[m, d] (* b[m, d]): bias / LayerScale / LayerNorm
+//                      parameter gradients, two deterministic stages (chunks, then one chunk over the partials)
+//   layernorm_bwd      dx (+ dx_add) and per-workgroup partial sums of dw, db
+//   gelu_bwd           dpre = dh * d/dx gelu_erf(pre)
+//   cross_entropy      mean softmax cross-entropy over the batch and its gradient (nn.CrossEntropyLoss, train.py:187)
+//   sumsq / clip_coef / scale   torch.nn.utils.clip_grad_norm_(parameters, 1.0) on one flat gradient buffer (train.py:222)
+//   adamw              torch.optim.AdamW update (train.py:68-72), one launch per parameter tensor
+//
+// Everything that reduces does so in a fixed order: results are bit-identical from run to run.
+#include "common.h"
+
+namespace {
+
+inline bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+inline unsigned stream_grid(int64_t items, int per = 256, int cap = 4096) {
+  int64_t g = (items + per - 1) / per;
+  return (unsigned)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+// ---- transpose: 32x32 tiles through LDS ------------------------------------------------------------------
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ src, int64_t lds_, float* __restrict__ dst,
+                                                        int64_t ldd, int M, int N, int Mpad) {
+  __shared__ float tile[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+  const int m0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + ty + 8 * i, n = n0 + tx;
+    tile[ty + 8 * i][tx] = (m < M && n < N) ? src[(int64_t)m * lds_ + n] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int n = n0 + ty + 8 * i, m = m0 + tx;
+    if (n < N && m < Mpad) dst[(int64_t)n * ldd + m] = tile[tx][ty + 8 * i];   // rows m >= M were loaded as zero
+  }
+}
+
+// ---- column sums ---------------------------------------------------------------------------------------------
+// workgroup = 64 columns x 4 row lanes; blockIdx.y = row chunk
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ a, int64_t lda, const float* __restrict__ b,
+                                                     int64_t ldb, float* __restrict__ out, int64_t ldo, int M, int D,
+                                                     int rows_per_chunk) {
+  __shared__ float sh[4][64];
+  const int col = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int rl = threadIdx.x >> 6;
+  const int r0 = blockIdx.y * rows_per_chunk;
+  int r1 = r0 + rows_per_chunk;
+  r1 = r1 < M ? r1 : M;
+  float s = 0.f;
+  if (col < D) {
+    for (int m = r0 + rl; m < r1; m += 4) {
+      const float v = a[(int64_t)m * lda + col];
+      s += b ? v * b[(int64_t)m * ldb + col] : v;
+    }
+  }
+  sh[rl][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (rl == 0 && col < D) out[(int64_t)blockIdx.y * ldo + col] = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
+}
+
+// ---- LayerNorm backward: one wave per row at a time, a workgroup of 4 waves strides over the rows ------------------
+constexpr int LN_MAXC = 4;   // 8-element chunks per lane: D <= 2048
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ x, int64_t ldx,
+                                                            const float* __restrict__ dy, int64_t lddy,
+                                                            const float* __restrict__ w, float eps,
+                                                            const float* __restrict__ dx_add, int64_t ldadd,
+                                                            float* __restrict__ dx, int64_t lddx,
+                                                            float* __restrict__ dwp, float* __restrict__ dbp, int M, int D) {
+  __shared__ float red[2][4][64 * 8];   // per wave, one 8-chunk at a time
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float wv[LN_MAXC][8], gw[LN_MAXC][8], gb[LN_MAXC][8];
+#pragma unroll
+  for (int t = 0; t < LN_MAXC; ++t) {
+    const int c = (lane + 64 * t) * 8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      wv[t][e] = c < D ? w[c + e] : 0.f;
+      gw[t][e] = 0.f;
+      gb[t][e] = 0.f;
+    }
+  }
+  const float inv_d = 1.0f / (float)D;
+  for (int m = blockIdx.x * 4 + wave; m < M; m += gridDim.x * 4) {
+    float xv[LN_MAXC][8], gv[LN_MAXC][8];
+    float s = 0.f;
+#pragma unroll
+    for (int t = 0; t < LN_MAXC; ++t) {
+      const int c = (lane + 64 * t) * 8;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        xv[t][e] = c < D ? x[(int64_t)m * ldx + c + e] : 0.f;
+        gv[t][e] = c < D ? dy[(int64_t)m * lddy + c + e] : 0.f;
+        s += xv[t][e];
+      }
+    }
+    const float mean = wave_sum(s) * inv_d;
+    float q = 0.f;
+#pragma unroll
+    for (int t = 0; t < LN_MAXC; ++t)
+      if ((lane + 64 * t) * 8 < D) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) q = fmaf(xv[t][e] - mean, xv[t][e] - mean, q);
+      }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) * inv_d + eps);
+    float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+    for (int t = 0; t < LN_MAXC; ++t)
+      if ((lane + 64 * t) * 8 < D) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float xh = (xv[t][e] - mean) * rstd;
+          const float g = gv[t][e] * wv[t][e];
+          gw[t][e] = fmaf(gv[t][e], xh, gw[t][e]);
+          gb[t][e] += gv[t][e];
+          xv[t][e] = xh;       // keep xhat
+          gv[t][e] = g;        // keep dy * w
+          c1 += g;
+          c2 = fmaf(g, xh, c2);
+        }
+      }
+    c1 = wave_sum(c1) * inv_d;
+    c2 = wave_sum(c2) * inv_d;
+#pragma unroll
+    for (int t = 0; t < LN_MAXC; ++t) {
+      const int c = (lane + 64 * t) * 8;
+      if (c < D) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float r = rstd * (gv[t][e] - c1 - xv[t][e] * c2);
+          if (dx_add) r += dx_add[(int64_t)m * ldadd + c + e];
+          dx[(int64_t)m * lddx + c + e] = r;
+        }
+      }
+    }
+  }
+  // the four waves' partial parameter gradients -> one row of the partial arrays per workgroup
+#pragma unroll
+  for (int t = 0; t < LN_MAXC; ++t) {
+    const int c = (lane + 64 * t) * 8;
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      red[0][wave][lane * 8 + e] = gw[t][e];
+      red[1][wave][lane * 8 + e] = gb[t][e];
+    }
+    __syncthreads();
+    if (wave == 0 && c < D) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int i = lane * 8 + e;
+        dwp[(int64_t)blockIdx.x * D + c + e] = (red[0][0][i] + red[0][1][i]) + (red[0][2][i] + red[0][3][i]);
+        dbp[(int64_t)blockIdx.x * D + c + e] = (red[1][0][i] + red[1][1][i]) + (red[1][2][i] + red[1][3][i]);
+      }
+    }
+  }
+}
+
+// ---- GELU backward ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gelu_bwd_kernel(const float* __restrict__ pre, int64_t ldp, const float* __restrict__ dh,
+                                                       int64_t ldh, float* __restrict__ dpre, int64_t ldd, int M, int D) {
+  const int64_t total = (int64_t)M * D;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t m = i / D;
+    const int c = (int)(i - m * D);
+    const float v = pre[m * ldp + c];
+    const float cdf = 0.5f * (1.0f + erf_as(v * 0.70710678118654752f));
+    const float pdf = 0.3989422804014327f * __expf(-0.5f * v * v);
+    dpre[m * ldd + c] = dh[m * ldh + c] * fmaf(v, pdf, cdf);
+  }
+}
+
+// ---- softmax cross-entropy, mean over the batch (one workgroup: the batch of logits is small) ------------------------
+__global__ __launch_bounds__(256) void cross_entropy_kernel(const float* __restrict__ logits, int64_t ld,
+                                                            const int64_t* __restrict__ labels, int B, int C,
+                                                            float* __restrict__ loss, float* __restrict__ dlogits, int64_t lddl) {
+  __shared__ float part[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float inv_b = 1.0f / (float)B;
+  float acc = 0.f;
+  for (int r = wave; r < B; r += 4) {
+    const float* row = logits + (int64_t)r * ld;
+    float mx = -3.0e38f;
+    for (int c = lane; c < C; c += 64) mx = fmaxf(mx, row[c]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s += __expf(row[c] - mx);
+    s = wave_sum(s);
+    const float lse = mx + __logf(s);
+    const int y = (int)labels[r];
+    if (lane == 0) acc += lse - row[y];
+    if (dlogits) {
+      const float is = 1.0f / s;
+      for (int c = lane; c < C; c += 64) dlogits[(int64_t)r * lddl + c] = (__expf(row[c] - mx) * is - (c == y ? 1.f : 0.f)) * inv_b;
+    }
+  }
+  if (lane == 0) part[wave] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) loss[0] = ((part[0] + part[1]) + (part[2] + part[3])) * inv_b;
+}
+
+// ---- gradient norm, clip coefficient, in-place scale ---------------------------------------------------------------
+constexpr int SUMSQ_PARTS = 1024;
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ parts) {
+  __shared__ float sh[4];
+  float s = 0.f;
+  const int64_t per = (n + gridDim.x - 1) / gridDim.x;
+  const int64_t lo = per * blockIdx.x;
+  int64_t hi = lo + per;
+  hi = hi < n ? hi : n;
+  for (int64_t i = lo + threadIdx.x; i < hi; i += 256) s = fmaf(x[i], x[i], s);
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) parts[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+// out[0] = total norm, out[1] = min(1, max_norm / (norm + 1e-6))   (torch.nn.utils.clip_grad_norm_)
+__global__ __launch_bounds__(64) void clip_coef_kernel(const float* __restrict__ parts, int nparts, float max_norm,
+                                                       float* __restrict__ out) {
+  float s = 0.f;
+  for (int i = threadIdx.x; i < nparts; i += 64) s += parts[i];
+  s = wave_sum(s);
+  if (threadIdx.x == 0) {
+    const float norm = sqrtf(s);
+    out[0] = norm;
+    out[1] = fminf(1.0f, max_norm / (norm + 1e-6f));
+  }
+}
+__global__ __launch_bounds__(256) void scale_by_kernel(float* __restrict__ x, int64_t n, const float* __restrict__ coef) {
+  const float c = coef[0];
+  if (c == 1.0f) return;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) x[i] *= c;
+}
+
+// ---- AdamW (decoupled weight decay, bias-corrected; torch.optim.AdamW with amsgrad=False, maximize=False) ------------
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                    float* __restrict__ v, int64_t n, float lr, float beta1, float beta2,
+                                                    float eps, float wd, float bc1, float bc2_sqrt) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float gi = g[i];
+    float pi = p[i] * (1.0f - lr * wd);
+    const float mi = fmaf(beta1, m[i], (1.0f - beta1) * gi);      // lerp(m, g, 1 - beta1)
+    const float vi = fmaf(beta2, v[i], (1.0f - beta2) * gi * gi);
+    m[i] = mi;
+    v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] = pi - (lr / bc1) * (mi / denom);
+  }
+}
+
+}  // namespace
+
+extern "C" int vitm_transpose_f32(const float* src, int64_t lds, float* dst, int64_t ldd, int M, int N, int m_pad,
+                                  vitm_stream_t stream) {
+  VITM_REQUIRE(src && dst, "vitm_transpose_f32: null pointer");
+  VITM_REQUIRE(M > 0 && N > 0 && lds >= N && m_pad >= M && ldd >= m_pad, "vitm_transpose_f32: bad shape");
+  dim3 grid((unsigned)((m_pad + 31) / 32), (unsigned)((N + 31) / 32));
+  VITM_REQUIRE(grid.y < 65536, "vitm_transpose_f32: N too large");
+  hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, (hipStream_t)stream, src, lds, dst, ldd, M, N, m_pad);
+  VITM_CHECK_LAUNCH("vitm_transpose_f32");
+  return VITM_OK;
+}
+
+extern "C" int vitm_colsum_f32(const float* a, int64_t lda, const float* b, int64_t ldb, float* out, int64_t ldo,
+                               int M, int D, int nchunks, vitm_stream_t stream) {
+  VITM_REQUIRE(a && out, "vitm_colsum_f32: null pointer");
+  VITM_REQUIRE(M > 0 && D > 0 && nchunks > 0 && nchunks < 65536 && lda >= D && ldo >= D && (!b || ldb >= D),
+               "vitm_colsum_f32: bad shape");
+  const int rpc = (M + nchunks - 1) / nchunks;
+  hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((D + 63) / 64), (unsigned)nchunks), dim3(256), 0, (hipStream_t)stream, a, lda,
+                     b, ldb, out, ldo, M, D, rpc);
+  VITM_CHECK_LAUNCH("vitm_colsum_f32");
+  return VITM_OK;
+}
+
+extern "C" int vitm_layernorm_bwd_f32(const float* x, int64_t ldx, const float* dy, int64_t lddy, const float* w, float eps,
+                                      const float* dx_add, int64_t ldadd, float* dx, int64_t lddx, float* dw_partial,
+                                      float* db_partial, int nblocks, int M, int D, vitm_stream_t stream) {
+  VITM_REQUIRE(x && dy && w && dx && dw_partial && db_partial, "vitm_layernorm_bwd_f32: null pointer");
+  VITM_REQUIRE(M > 0 && D > 0 && D % 8 == 0 && D <= 64 * 8 * LN_MAXC, "vitm_layernorm_bwd_f32: D=%d must be a multiple of 8 and <= %d", D, 64 * 8 * LN_MAXC);
+  VITM_REQUIRE(ldx >= D && lddy >= D && lddx >= D && (!dx_add || ldadd >= D) && nblocks > 0, "vitm_layernorm_bwd_f32: bad leading dimension");
+  hipLaunchKernelGGL(layernorm_bwd_kernel, dim3((unsigned)nblocks), dim3(256), 0, (hipStream_t)stream, x, ldx, dy, lddy, w, eps,
+                     dx_add, ldadd, dx, lddx, dw_partial, db_partial, M, D);
+  VITM_CHECK_LAUNCH("vitm_layernorm_bwd_f32");
+  return VITM_OK;
+}
+
+extern "C" int vitm_gelu_bwd_f32(const float* pre, int64_t ldp, const float* dh, int64_t ldh, float* dpre, int64_t ldd, int M,
+                                 int D, vitm_stream_t stream) {
+  VITM_REQUIRE(pre && dh && dpre, "vitm_gelu_bwd_f32: null pointer");
+  VITM_REQUIRE(M > 0 && D > 0 && ldp >= D && ldh >= D && ldd >= D, "vitm_gelu_bwd_f32: bad shape");
+  hipLaunchKernelGGL(gelu_bwd_kernel, dim3(stream_grid((int64_t)M * D)), dim3(256), 0, (hipStream_t)stream, pre, ldp, dh, ldh, dpre,
+                     ldd, M, D);
+  VITM_CHECK_LAUNCH("vitm_gelu_bwd_f32");
+  return VITM_OK;
+}
+
+extern "C" int vitm_cross_entropy_f32(const float* logits, int64_t ld, const int64_t* labels, int B, int C, float* loss,
+                                      float* dlogits, int64_t lddl, vitm_stream_t stream) {
+  VITM_REQUIRE(logits && labels && loss, "vitm_cross_entropy_f32: null pointer");
+  VITM_REQUIRE(B > 0 && C > 0 && ld >= C && (!dlogits || lddl >= C), "vitm_cross_entropy_f32: bad shape");
+  hipLaunchKernelGGL(cross_entropy_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, logits, ld, labels, B, C, loss, dlogits, lddl);
+  VITM_CHECK_LAUNCH("vitm_cross_entropy_f32");
+  return VITM_OK;
+}
+
+extern "C" int vitm_grad_clip_f32(float* grads, int64_t n, float max_norm, float* scratch, float* norm_and_coef,
+                                  vitm_stream_t stream) {
+  VITM_REQUIRE(grads && scratch && norm_and_coef, "vitm_grad_clip_f32: null pointer");
+  VITM_REQUIRE(n > 0 && max_norm > 0.f, "vitm_grad_clip_f32: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(sumsq_kernel, dim3(SUMSQ_PARTS), dim3(256), 0, st, grads, n, scratch);
+  hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(64), 0, st, scratch, SUMSQ_PARTS, max_norm, norm_and_coef);
+  hipLaunchKernelGGL(scale_by_kernel, dim3(stream_grid(n)), dim3(256), 0, st, grads, n, norm_and_coef + 1);
+  VITM_CHECK_LAUNCH("vitm_grad_clip_f32");
+  return VITM_OK;
+}
+extern "C" int vitm_grad_clip_scratch_floats(void) { return SUMSQ_PARTS; }
+
+extern "C" int vitm_adamw_f32(float* p, const float* g, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
+                              float beta2, float eps, float weight_decay, int step, vitm_stream_t stream) {
+  VITM_REQUIRE(p && g && exp_avg && exp_avg_sq, "vitm_adamw_f32: null pointer");
+  VITM_REQUIRE(n > 0 && step > 0, "vitm_adamw_f32: n and step must be positive");
+  const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+  hipLaunchKernelGGL(adamw_kernel, dim3(stream_grid(n)), dim3(256), 0, (hipStream_t)stream, p, g, exp_avg, exp_avg_sq, n, lr, beta1,
+                     beta2, eps, weight_decay, (float)bc1, (float)sqrt(bc2));
+  VITM_CHECK_LAUNCH("vitm_adamw_f32");
+  return VITM_OK;
+}

@@ -56,6 +56,20 @@ SIGNATURES = {
     "vitm_im2col": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int64, c_int, c_int,
                             c_void_p]),
     "vitm_gelu": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
+    "vitm_attention_f32_lse": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int, c_int, c_int, c_int, c_float,
+                                       c_void_p]),
+    "vitm_attention_bwd_f32": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64,
+                                       c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p]),
+    "vitm_transpose_f32": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
+    "vitm_colsum_f32": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
+    "vitm_layernorm_bwd_f32": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_float, c_void_p, c_int64, c_void_p,
+                                       c_int64, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "vitm_gelu_bwd_f32": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_void_p]),
+    "vitm_cross_entropy_f32": (c_int, [c_void_p, c_int64, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int64, c_void_p]),
+    "vitm_grad_clip_f32": (c_int, [c_void_p, c_int64, c_float, c_void_p, c_void_p, c_void_p]),
+    "vitm_grad_clip_scratch_floats": (c_int, []),
+    "vitm_adamw_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float, c_float,
+                               c_int, c_void_p]),
     "vitm_cast_f32_to_bf16": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "vitm_cast_bf16_to_f32": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
 }

@@ -1,0 +1,128 @@
+"""Torch-tensor front end of the fp32 training entry points of the C ABI (backward pieces, loss, clip, AdamW)."""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._ops import _p, _stream, round_up, k_multiple, pack_linear, gemm, EPI_BIAS
+
+COLSUM_CHUNKS = 64
+LN_BWD_BLOCKS = 256
+
+
+def _f32(t: torch.Tensor) -> torch.Tensor:
+    assert t.dtype == torch.float32 and t.stride(-1) == 1, "fp32 row-major tensor expected"
+    return t
+
+
+def attention_lse(qkv, out, lse, B, N, H, hd, scale) -> None:
+    _lib.check(_lib.load().vitm_attention_f32_lse(_p(_f32(qkv)), qkv.stride(0), _p(_f32(out)), out.stride(0), _p(lse), B, N, H,
+                                                  hd, float(scale), _stream()), "vitm_attention_f32_lse")
+
+
+def attention_bwd(qkv, o, d_o, lse, dqkv, B, N, H, hd, scale) -> None:
+    delta = torch.empty(B * H * N, dtype=torch.float32, device=qkv.device)
+    _lib.check(_lib.load().vitm_attention_bwd_f32(_p(_f32(qkv)), qkv.stride(0), _p(_f32(o)), o.stride(0), _p(_f32(d_o)),
+                                                  d_o.stride(0), _p(lse), _p(_f32(dqkv)), dqkv.stride(0), _p(delta), B, N, H,
+                                                  hd, float(scale), _stream()), "vitm_attention_bwd_f32")
+
+
+def transpose(src: torch.Tensor, M: int, N: int, m_pad: Optional[int] = None) -> torch.Tensor:
+    """[M, N] (row stride src.stride(0)) -> new [N, m_pad] with the pad columns zero."""
+    m_pad = M if m_pad is None else m_pad
+    dst = torch.empty((N, m_pad), dtype=torch.float32, device=src.device)
+    _lib.check(_lib.load().vitm_transpose_f32(_p(_f32(src)), src.stride(0), _p(dst), m_pad, M, N, m_pad, _stream()),
+               "vitm_transpose_f32")
+    return dst
+
+
+def colsum(a: torch.Tensor, M: int, D: int, b: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[d] = sum_m a[m, d] * (b[m, d] if b is given else 1), deterministic two-stage reduction."""
+    lib = _lib.load()
+    if out is None:
+        out = torch.empty(D, dtype=torch.float32, device=a.device)
+    nch = min(COLSUM_CHUNKS, M)
+    if nch > 1:
+        part = torch.empty((nch, D), dtype=torch.float32, device=a.device)
+        _lib.check(lib.vitm_colsum_f32(_p(_f32(a)), a.stride(0), _p(b), 0 if b is None else b.stride(0), _p(part), D, M, D, nch,
+                                       _stream()), "vitm_colsum_f32")
+        _lib.check(lib.vitm_colsum_f32(_p(part), D, None, 0, _p(out), D, nch, D, 1, _stream()), "vitm_colsum_f32")
+    else:
+        _lib.check(lib.vitm_colsum_f32(_p(_f32(a)), a.stride(0), _p(b), 0 if b is None else b.stride(0), _p(out), D, M, D, 1,
+                                       _stream()), "vitm_colsum_f32")
+    return out
+
+
+def layernorm_bwd(x, dy, w, eps, M, D, dx, dx_add=None, dw_out=None, db_out=None):
+    """dx (= dx_add + LayerNorm backward) and, when dw_out / db_out are given, the parameter gradients."""
+    nb = min(LN_BWD_BLOCKS, (M + 3) // 4)
+    dwp = torch.empty((nb, D), dtype=torch.float32, device=x.device)
+    dbp = torch.empty((nb, D), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().vitm_layernorm_bwd_f32(
+        _p(_f32(x)), x.stride(0), _p(_f32(dy)), dy.stride(0), _p(w), float(eps), _p(dx_add),
+        0 if dx_add is None else dx_add.stride(0), _p(_f32(dx)), dx.stride(0), _p(dwp), _p(dbp), nb, M, D, _stream()),
+        "vitm_layernorm_bwd_f32")
+    if dw_out is not None:
+        colsum(dwp, nb, D, out=dw_out)
+    if db_out is not None:
+        colsum(dbp, nb, D, out=db_out)
+
+
+def gelu_bwd(pre, dh, dpre, M, D) -> None:
+    _lib.check(_lib.load().vitm_gelu_bwd_f32(_p(_f32(pre)), pre.stride(0), _p(_f32(dh)), dh.stride(0), _p(_f32(dpre)),
+                                             dpre.stride(0), M, D, _stream()), "vitm_gelu_bwd_f32")
+
+
+def cross_entropy(logits, labels, want_grad=True):
+    """(loss scalar tensor, dlogits or None): mean softmax cross-entropy over the batch."""
+    B, C = logits.shape
+    loss = torch.empty(1, dtype=torch.float32, device=logits.device)
+    dl = torch.empty((B, C), dtype=torch.float32, device=logits.device) if want_grad else None
+    lab = labels.to(torch.int64).contiguous()
+    _lib.check(_lib.load().vitm_cross_entropy_f32(_p(_f32(logits)), logits.stride(0), _p(lab), B, C, _p(loss), _p(dl),
+                                                  C, _stream()), "vitm_cross_entropy_f32")
+    return loss, dl
+
+
+def grad_clip(flat_grads: torch.Tensor, max_norm: float) -> torch.Tensor:
+    """In-place clip of one flat fp32 gradient buffer; returns a 2-element tensor (norm, coefficient)."""
+    lib = _lib.load()
+    scratch = torch.empty(lib.vitm_grad_clip_scratch_floats(), dtype=torch.float32, device=flat_grads.device)
+    nc = torch.empty(2, dtype=torch.float32, device=flat_grads.device)
+    _lib.check(lib.vitm_grad_clip_f32(_p(flat_grads), flat_grads.numel(), float(max_norm), _p(scratch), _p(nc), _stream()),
+               "vitm_grad_clip_f32")
+    return nc
+
+
+def adamw(p, g, m, v, lr, beta1, beta2, eps, wd, step) -> None:
+    _lib.check(_lib.load().vitm_adamw_f32(_p(p), _p(g), _p(m), _p(v), p.numel(), float(lr), float(beta1), float(beta2),
+                                          float(eps), float(wd), int(step), _stream()), "vitm_adamw_f32")
+
+
+# ---- Linear backward out of the forward GEMM ----------------------------------------------------------------------
+def linear_dx(dy: torch.Tensor, weight: torch.Tensor, M: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """dx[M, K] = dy[M, N] . W[N, K]  (nn.Linear weight layout): the forward GEMM with W^T as the packed operand."""
+    N, K = weight.shape
+    wt = transpose(weight.detach().contiguous(), N, K)              # [K, N]
+    pk = pack_linear(wt, None, dtype=torch.float32)                 # rows K (padded to 8), cols N (padded to 64)
+    dyp = dy
+    if dy.shape[1] < pk.kpad:                                       # pad dy's columns to the GEMM's K multiple
+        dyp = torch.zeros((M, pk.kpad), dtype=torch.float32, device=dy.device)
+        dyp[:, :dy.shape[1]] = dy
+    if out is None:
+        out = torch.empty((M, pk.npad), dtype=torch.float32, device=dy.device)
+    gemm(dyp, pk, out, EPI_BIAS, M)
+    return out
+
+
+def linear_dw(dy: torch.Tensor, x: torch.Tensor, M: int, N: int, K: int) -> torch.Tensor:
+    """dW[N, K] = dy[:, :N]^T . x[:, :K]: the forward GEMM on the two transposed activations (rows padded to its K multiple)."""
+    mp = round_up(M, k_multiple())
+    dyt = transpose(dy, M, N, mp)                                   # [N, mp]
+    xt = transpose(x, M, K, mp)                                     # [K, mp]
+    pk = pack_linear(xt, None, dtype=torch.float32)                 # "weight" = x^T: rows K, cols mp
+    out = torch.empty((N, pk.npad), dtype=torch.float32, device=dy.device)
+    gemm(dyt, pk, out, EPI_BIAS, N)
+    return out[:, :K]
