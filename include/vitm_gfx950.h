@@ -116,12 +116,12 @@ int vitm_gemm_uses_big_tile(int M, int N, int K);
 
 /*
  * Patch matrix for vitm_gemm: out[(b, cls_slot + patch), k] = img[b, c, py*ph+ky, px*pw+kx], k = (c, ky, kx) in
- * Conv2d.weight.reshape(D, -1) order, bf16, K padded with zeros to kpad; with cls_slot = 1 row 0 of every image
+ * Conv2d.weight.reshape(D, -1) order, bf16 or fp32 (out_dtype), K padded with zeros to kpad; with cls_slot = 1 row 0 of every image
  * is a zero row (the GEMM then leaves bias there; vitm_embed_finalize overwrites it with the class token).
  * img is NCHW bf16 or fp32.  First half of PatchEmbed.forward's Conv2d (patch_embeddings.py:115) at large batch.
  */
 int vitm_im2col(const void* img, int img_dtype, int B, int C, int H, int W, int ph, int pw, void* out,
-                int64_t ldo, int kpad, int cls_slot, vitm_stream_t stream);
+                int out_dtype, int64_t ldo, int kpad, int cls_slot, vitm_stream_t stream);
 
 /*
  * Full-precision GEMM: as vitm_gemm with A, Wp, out and resid all fp32 and the fp32 matrix
@@ -239,6 +239,10 @@ int vitm_colsum_f32(const float* a, int64_t lda, const float* b, int64_t ldb, fl
 int vitm_layernorm_bwd_f32(const float* x, int64_t ldx, const float* dy, int64_t lddy, const float* w, float eps,
                            const float* dx_add, int64_t ldadd, float* dx, int64_t lddx, float* dw_partial,
                            float* db_partial, int nblocks, int M, int D, vitm_stream_t stream);
+
+/* out[m,d] = resid[m,d] + gamma[d] * z[m,d]: LayerScale + residual add with the branch output kept (models.py:209-210). */
+int vitm_residual_scale_f32(const float* resid, int64_t ldr, const float* z, int64_t ldz, const float* gamma, float* out,
+                            int64_t ldo, int M, int D, vitm_stream_t stream);
 
 /* dpre = dh * d/dx gelu_erf(pre): backward of nn.GELU() (models.py:128). */
 int vitm_gelu_bwd_f32(const float* pre, int64_t ldp, const float* dh, int64_t ldh, float* dpre, int64_t ldd, int M,

@@ -257,8 +257,8 @@ int launch_qk_norm(void* qkv, int64_t ld, int M, int H, int hd, const float* qw,
 
 // Patch matrix of an NCHW image batch (bf16 out): row (b, cls + patch) holds the patch's (c, ky, kx) values in the
 // order of Conv2d.weight.reshape(D, -1); the class-token row (when cls = 1) and the K padding are zero.
-template <typename TI>
-__global__ __launch_bounds__(256) void im2col_kernel(const TI* __restrict__ img, bf16_t* __restrict__ out, int64_t ldo,
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void im2col_kernel(const TI* __restrict__ img, TO* __restrict__ out, int64_t ldo,
                                                      int64_t rows, int C, int H, int W, int ph, int pw, int gw,
                                                      int npatch, int kreal, int kpad, int cls, int vec) {
   const int cpr = kpad / 8;
@@ -463,9 +463,10 @@ extern "C" int vitm_qk_norm(void* qkv, int dtype, int64_t ldqkv, int M, int H, i
 }
 
 extern "C" int vitm_im2col(const void* img, int img_dtype, int B, int C, int H, int W, int ph, int pw, void* out,
-                           int64_t ldo, int kpad, int cls_slot, vitm_stream_t stream) {
+                           int out_dtype, int64_t ldo, int kpad, int cls_slot, vitm_stream_t stream) {
   VITM_REQUIRE(img && out, "vitm_im2col: null pointer");
   VITM_REQUIRE(img_dtype == VITM_BF16 || img_dtype == VITM_F32, "vitm_im2col: bad img_dtype %d", img_dtype);
+  VITM_REQUIRE(out_dtype == VITM_BF16 || out_dtype == VITM_F32, "vitm_im2col: bad out_dtype %d", out_dtype);
   VITM_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && ph > 0 && pw > 0, "vitm_im2col: bad shape");
   const int gh = H / ph, gw = W / pw;
   VITM_REQUIRE(gh > 0 && gw > 0, "vitm_im2col: patch larger than the image");
@@ -475,13 +476,14 @@ extern "C" int vitm_im2col(const void* img, int img_dtype, int B, int C, int H, 
   const int64_t rows = (int64_t)B * (gh * gw + (cls_slot ? 1 : 0));
   const dim3 grid(stream_grid(rows * (kpad / 8)));
   hipStream_t st = (hipStream_t)stream;
-  if (img_dtype == VITM_F32) {
-    hipLaunchKernelGGL(im2col_kernel<float>, grid, dim3(256), 0, st, (const float*)img, (bf16_t*)out, ldo, rows, C, H, W, ph, pw,
-                       gw, gh * gw, kreal, kpad, cls_slot ? 1 : 0, vec);
-  } else {
-    hipLaunchKernelGGL(im2col_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)img, (bf16_t*)out, ldo, rows, C, H, W, ph,
-                       pw, gw, gh * gw, kreal, kpad, cls_slot ? 1 : 0, vec);
-  }
+#define VITM_IM2COL(TI, TO)                                                                                         \
+  hipLaunchKernelGGL((im2col_kernel<TI, TO>), grid, dim3(256), 0, st, (const TI*)img, (TO*)out, ldo, rows, C, H, W, ph, pw, \
+                     gw, gh * gw, kreal, kpad, cls_slot ? 1 : 0, vec)
+  if (img_dtype == VITM_F32 && out_dtype == VITM_BF16) VITM_IM2COL(float, bf16_t);
+  else if (img_dtype == VITM_F32) VITM_IM2COL(float, float);
+  else if (out_dtype == VITM_BF16) VITM_IM2COL(bf16_t, bf16_t);
+  else VITM_IM2COL(bf16_t, float);
+#undef VITM_IM2COL
   VITM_CHECK_LAUNCH("vitm_im2col");
   return VITM_OK;
 }

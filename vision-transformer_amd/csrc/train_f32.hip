@@ -174,6 +174,18 @@ __global__ __launch_bounds__(256) void gelu_bwd_kernel(const float* __restrict__
   }
 }
 
+// ---- LayerScale + residual add that keeps the branch output -------------------------------------------------------
+__global__ __launch_bounds__(256) void residual_scale_kernel(const float* __restrict__ r, int64_t ldr, const float* __restrict__ z,
+                                                             int64_t ldz, const float* __restrict__ g, float* __restrict__ out,
+                                                             int64_t ldo, int M, int D) {
+  const int64_t total = (int64_t)M * D;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t m = i / D;
+    const int c = (int)(i - m * D);
+    out[m * ldo + c] = fmaf(g[c], z[m * ldz + c], r[m * ldr + c]);
+  }
+}
+
 // ---- softmax cross-entropy, mean over the batch (one workgroup: the batch of logits is small) ------------------------
 __global__ __launch_bounds__(256) void cross_entropy_kernel(const float* __restrict__ logits, int64_t ld,
                                                             const int64_t* __restrict__ labels, int B, int C,
@@ -297,6 +309,16 @@ extern "C" int vitm_gelu_bwd_f32(const float* pre, int64_t ldp, const float* dh,
   hipLaunchKernelGGL(gelu_bwd_kernel, dim3(stream_grid((int64_t)M * D)), dim3(256), 0, (hipStream_t)stream, pre, ldp, dh, ldh, dpre,
                      ldd, M, D);
   VITM_CHECK_LAUNCH("vitm_gelu_bwd_f32");
+  return VITM_OK;
+}
+
+extern "C" int vitm_residual_scale_f32(const float* resid, int64_t ldr, const float* z, int64_t ldz, const float* gamma, float* out,
+                                       int64_t ldo, int M, int D, vitm_stream_t stream) {
+  VITM_REQUIRE(resid && z && gamma && out, "vitm_residual_scale_f32: null pointer");
+  VITM_REQUIRE(M > 0 && D > 0 && ldr >= D && ldz >= D && ldo >= D, "vitm_residual_scale_f32: bad shape");
+  hipLaunchKernelGGL(residual_scale_kernel, dim3(stream_grid((int64_t)M * D)), dim3(256), 0, (hipStream_t)stream, resid, ldr, z, ldz,
+                     gamma, out, ldo, M, D);
+  VITM_CHECK_LAUNCH("vitm_residual_scale_f32");
   return VITM_OK;
 }
 

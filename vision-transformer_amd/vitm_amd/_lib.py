@@ -53,8 +53,10 @@ SIGNATURES = {
                                c_float, c_void_p]),
     "vitm_scale_channels": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_void_p]),
     "vitm_gemm_uses_big_tile": (c_int, [c_int, c_int, c_int]),
-    "vitm_im2col": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int64, c_int, c_int,
+    "vitm_im2col": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int64, c_int, c_int,
                             c_void_p]),
+    "vitm_residual_scale_f32": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int, c_int,
+                                        c_void_p]),
     "vitm_gelu": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
     "vitm_attention_f32_lse": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int, c_int, c_int, c_int, c_float,
                                        c_void_p]),

@@ -154,6 +154,13 @@ def gemm(A: torch.Tensor, pk: PackedLinear, out: torch.Tensor, epilogue: int, M:
     return out
 
 
+def im2col(img: torch.Tensor, A: torch.Tensor, patch, kpad: int, cls_slot: bool) -> None:
+    """Patch matrix of an NCHW batch into A [rows, kpad] (bf16 or fp32); class-token rows (cls_slot) and K padding zero."""
+    B, C, H, W = img.shape
+    _lib.check(_lib.load().vitm_im2col(_p(img), _dt(img), B, C, H, W, patch[0], patch[1], _p(A), _dt(A), A.stride(0), kpad,
+                                       1 if cls_slot else 0, _stream()), "vitm_im2col")
+
+
 def patch_embed(img: torch.Tensor, pk: PackedLinear, tokens: torch.Tensor, patch, D: int, cls_slot: bool) -> None:
     B, C, H, W = img.shape
     if tokens.dtype == torch.bfloat16 and pk.npad == D:
@@ -163,8 +170,7 @@ def patch_embed(img: torch.Tensor, pk: PackedLinear, tokens: torch.Tensor, patch
         lib = _lib.load()
         if lib.vitm_gemm_uses_big_tile(rows, pk.npad, pk.kpad):
             A = torch.empty((rows, pk.kpad), dtype=torch.bfloat16, device=img.device)
-            _lib.check(lib.vitm_im2col(_p(img), _dt(img), B, C, H, W, patch[0], patch[1], _p(A), pk.kpad, pk.kpad,
-                                       1 if cls_slot else 0, _stream()), "vitm_im2col")
+            im2col(img, A, patch, pk.kpad, cls_slot)
             gemm(A, pk, tokens, EPI_BIAS, rows)
             return
     if tokens.dtype == torch.float32:

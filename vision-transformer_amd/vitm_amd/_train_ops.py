@@ -75,6 +75,11 @@ def gelu_bwd(pre, dh, dpre, M, D) -> None:
                                              dpre.stride(0), M, D, _stream()), "vitm_gelu_bwd_f32")
 
 
+def residual_scale(resid, z, gamma, out, M, D) -> None:
+    _lib.check(_lib.load().vitm_residual_scale_f32(_p(_f32(resid)), resid.stride(0), _p(_f32(z)), z.stride(0), _p(gamma),
+                                                   _p(_f32(out)), out.stride(0), M, D, _stream()), "vitm_residual_scale_f32")
+
+
 def cross_entropy(logits, labels, want_grad=True):
     """(loss scalar tensor, dlogits or None): mean softmax cross-entropy over the batch."""
     B, C = logits.shape
