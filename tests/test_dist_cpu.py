@@ -63,3 +63,47 @@ def test_two_rank_batch_sharding_equals_unsharded_forward():
     assert same, "sharded forward differs from the unsharded one"
     assert sorted(bounds) == [(0, 3), (3, 5)]
     assert slow == 2.0
+
+
+def _allreduce_worker(rank, world, port, q):
+    import os
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from vitm_amd.training import FlatGradients
+        torch.manual_seed(0)
+        lin = torch.nn.Sequential(torch.nn.Linear(5, 3), torch.nn.LayerNorm(3))
+        fg = FlatGradients(lin.parameters())
+        # every parameter's .grad is a view into the flat buffer, in parameter order
+        off = 0
+        for p in lin.parameters():
+            assert p.grad.data_ptr() == fg.flat.data_ptr() + 4 * off and p.grad.shape == p.shape
+            off += p.numel()
+        for i, p in enumerate(lin.parameters()):
+            p.grad.fill_(float(rank + 1) * (i + 1))
+        fg.all_reduce()
+        want = sum(r + 1 for r in range(world)) / world
+        ok = all(torch.allclose(p.grad, torch.full_like(p, want * (i + 1))) for i, p in enumerate(lin.parameters()))
+        lin.zero_grad(set_to_none=True)
+        fg.zero()                      # views are re-attached and zeroed
+        ok = ok and all(p.grad is not None and float(p.grad.abs().sum()) == 0.0 for p in lin.parameters())
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_flat_gradient_allreduce_two_ranks():
+    """The data-parallel gradient exchange of the training step (one flat buffer, averaged), rehearsed over gloo."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000) + 7
+    procs = [ctx.Process(target=_allreduce_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    assert res == [(0, True), (1, True)]

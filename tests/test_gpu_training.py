@@ -1,0 +1,111 @@
+"""The training step on a real MI355X against the fixture captured from the imported reference
+(tests/golden/make_golden_train.py: three iterations of the loop body of vitm/training/train.py:215-224 on the
+``tiny2`` configuration, fp32 CPU).  Bars: loss and gradient norm 1e-4 relative; every parameter gradient of step 1
+within 1e-4 of the largest gradient entry of that tensor (2e-4 for the deepest ones); parameters after three AdamW
+steps within 2e-5 absolute (the update is lr-sized: 1e-5 .. 1.4e-5)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+import weights as W
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _model(cfg, seed):
+    from vitm_amd.models import VisionTransformer, VITC
+    LN = nn.LayerNorm
+    vt = VisionTransformer(cfg["image_size"], patch_size=cfg["patch_size"], num_classes=cfg["num_classes"],
+                           num_heads=cfg["num_heads"], mlp_ratio=cfg["mlp_ratio"], depth=cfg["depth"],
+                           embed_dim=cfg["embed_dim"], norm_layer=LN, embed_norm_layer=LN if cfg["embed_norm"] else None,
+                           final_norm_layer=LN if cfg["final_norm"] else None)
+    m = VITC(vt).train()
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in W.make_state_dict(cfg, seed).items()}, strict=True)
+    return m.cuda()
+
+
+def test_training_steps_match_reference():
+    from vitm_amd import training
+    g = np.load(os.path.join(GOLD, "train_tiny2.npz"))
+    cfg = W.CONFIGS["tiny2"]
+    seed, batch, steps = int(g["seed"]), int(g["batch"]), int(g["steps"])
+    model = _model(cfg, seed)
+    opt, sched = training.reference_optimizer_and_scheduler(model, 1000)
+    tr = training.Trainer(model, opt, sched, max_norm=1.0)
+    for step in range(steps):
+        x = torch.from_numpy(W.make_input(cfg, batch, seed + 10 + step)).cuda()
+        y = torch.from_numpy(g[f"labels{step}"]).cuda()
+        if step == 0:   # raw gradients of the first step, through the plain autograd interface
+            tr.grads.zero()
+            logits = model(x)
+            assert logits.requires_grad and logits.shape == (batch, cfg["num_classes"])
+            loss = training.CrossEntropyLoss()(logits, y)
+            loss.backward()
+            assert abs(loss.item() - g["losses"][0]) <= 1e-4 * abs(g["losses"][0])
+            worst = 0.0
+            for k, p in model.named_parameters():
+                ref = torch.from_numpy(g["grad." + k])
+                assert p.grad is not None and p.grad.shape == ref.shape, k
+                err = (p.grad.cpu() - ref).abs().max().item() / max(ref.abs().max().item(), 1e-12)
+                worst = max(worst, err)
+                assert err <= 2e-4, f"{k}: gradient relative error {err:.3g}"
+            print("worst relative gradient error", worst)
+        assert abs(opt.param_groups[0]["lr"] - g["lrs"][step]) <= 1e-12
+        loss = tr.step(x, y)
+        assert abs(loss.item() - g["losses"][step]) <= 1e-4 * abs(g["losses"][step]), (step, loss.item())
+        assert abs(tr.last_grad_norm.item() - g["grad_norms"][step]) <= 2e-4 * g["grad_norms"][step], step
+    for k, p in model.named_parameters():
+        ref = torch.from_numpy(g["param." + k])
+        assert (p.detach().cpu() - ref).abs().max().item() <= 2e-5, k
+    # the optimizer state has torch's layout
+    sd = opt.state_dict()
+    assert set(sd["state"][0]) == {"step", "exp_avg", "exp_avg_sq"} and float(sd["state"][0]["step"]) == steps
+
+
+def test_training_without_optional_norms_and_with_padding(monkeypatch):
+    """No embed / pre / final norm, head_dim 96 with a hidden width (614) that needs padding, against float64 autograd
+    of the CPU oracle."""
+    from oracle import vit_oracle as O
+    from vitm_amd import training
+    from vitm_amd.models import VisionTransformer, VITC
+    vt = VisionTransformer(32, patch_size=4, num_classes=10, num_heads=2, mlp_ratio=0.8, depth=2, embed_dim=192)
+    model = VITC(vt).train()
+    torch.manual_seed(3)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if n.endswith("gamma"):
+                p.copy_(1.0 + 0.1 * torch.randn_like(p))
+            elif n.endswith("bias"):
+                p.normal_(0, 0.1)
+    sd64 = {k: v.detach().double().requires_grad_(True) for k, v in model.state_dict().items()}
+    x = torch.randn(5, 3, 32, 32)
+    y = torch.tensor([1, 0, 9, 3, 3])
+    ocfg = dict(image_size=(32, 32), patch_size=(4, 4), num_heads=2, depth=2)
+    # the oracle reads its weights detached; for this test it must keep the autograd graph
+    monkeypatch.setattr(O, "_t", lambda sd, key, dtype: None if sd.get(key) is None else sd[key].to(dtype))
+    logits64 = O.vitc_forward(x.double(), sd64, ocfg, dtype=torch.float64)
+    loss64 = torch.nn.functional.cross_entropy(logits64, y)
+    loss64.backward()
+    model = model.cuda()
+    logits = model(x.cuda())
+    loss = training.CrossEntropyLoss()(logits, y.cuda())
+    loss.backward()
+    assert abs(loss.item() - loss64.item()) <= 1e-4 * abs(loss64.item())
+    for k, p in model.named_parameters():
+        ref = sd64[k].grad
+        err = (p.grad.cpu().double() - ref).abs().max().item() / max(ref.abs().max().item(), 1e-12)
+        assert err <= 2e-4, f"{k}: {err:.3g}"
+
+
+def test_inference_path_unchanged_under_no_grad():
+    model = _model(W.CONFIGS["tiny2"], 1)
+    x = torch.from_numpy(W.make_input(W.CONFIGS["tiny2"], 3, 2)).cuda()
+    with torch.no_grad():
+        a = model(x)
+    b = model(x)
+    assert not a.requires_grad and b.requires_grad
+    assert (a - b.detach()).abs().max().item() <= 1e-4 * a.abs().max().item()

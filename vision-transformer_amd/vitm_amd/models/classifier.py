@@ -2,7 +2,8 @@
 
 API mirror of the reference's ``VITC`` (vitm/models/classifier.py:6-39): ``VITC(vit_model)`` with
 attributes ``vit_model`` and ``head = nn.Linear(embed_dim, num_classes)`` and state_dict keys
-``vit_model.*``, ``head.{weight,bias}``.  When the backbone is this package's ``VisionTransformer`` the final
+``vit_model.*``, ``head.{weight,bias}``.  With autograd enabled, fp32 images and fp32 parameters that require
+gradients, ``forward`` returns logits carrying a graph (``vitm_amd.training``); otherwise it is inference.  When the backbone is this package's ``VisionTransformer`` the final
 LayerNorm is applied to the class-token rows only (folded into the head GEMM on the bf16 path).
 """
 from __future__ import annotations
@@ -24,6 +25,11 @@ class VITC(nn.Module):
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         """(B, C, H, W) images -> (B, num_classes) logits, in the dtype of ``x``."""
         _ops.require_cuda(x, "VITC.forward")
+        if torch.is_grad_enabled() and x.dtype == torch.float32 and any(p.requires_grad for p in self.parameters()):
+            # training: the fp32 forward that keeps its activations, with a hand-written backward behind it
+            from .. import training
+            if training.supported(self) is None and all(p.dtype == torch.float32 for p in self.parameters()):
+                return training.vitc_forward_with_grad(self, x)
         vt = self.vit_model
         C = self.head.out_features
         with torch.cuda.device(x.device):

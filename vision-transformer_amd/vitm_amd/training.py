@@ -1,0 +1,463 @@
+"""The training step of ``VITC`` on MI355X, fp32.
+
+Counterpart of the loop body of the reference's vitm/training/train.py:215-224::
+
+    optimizer.zero_grad(); outputs = vitc(inputs); loss = criterion(outputs, labels); loss.backward()
+    torch.nn.utils.clip_grad_norm_(vitc.parameters(), max_norm=1.0); optimizer.step(); scheduler.step()
+
+with every tensor operation in hand-written HIP kernels: the forward keeps the activations the backward needs, the
+backward is written out by hand (GEMMs of the forward kernel family on transposed operands, fp32 attention backward,
+LayerNorm / GELU backward, deterministic column-sum reductions), the loss, the gradient clip and the AdamW update are
+kernels too.  The reference trains in fp32 (no autocast), so does this path.  PyTorch supplies memory, the autograd
+hook-up (one ``autograd.Function`` for the whole model, one for the loss) and, for data parallelism, the RCCL
+all-reduce of the flat gradient buffer.
+
+Supported: ``VITC(VisionTransformer)`` built from this package's sequential ``Block`` with LayerNorm (or Identity)
+norms, learnable position embedding, GELU MLP, no qk-norm -- the configuration the reference's training script builds
+(train.py:167-177).
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+import torch
+import torch.nn as nn
+
+from . import _ops
+from . import _train_ops as T
+from .models.models import Block, VisionTransformer, _check_gelu
+from .models.patch_embeddings import PatchEmbed, layernorm_params
+
+F32 = torch.float32
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# small helpers
+# ----------------------------------------------------------------------------------------------------------------
+def _ld(D: int) -> int:
+    return _ops.round_up(D, _ops.k_multiple())
+
+
+def _buf(M: int, width: int, device, like_width: Optional[int] = None) -> torch.Tensor:
+    """[M, roundup(width, 64)] fp32; zero-filled when it has pad columns (they feed GEMMs as K padding)."""
+    w = _ld(width)
+    return torch.zeros((M, w), dtype=F32, device=device) if w != width else torch.empty((M, w), dtype=F32, device=device)
+
+
+def _pk(w: torch.Tensor, b: Optional[torch.Tensor]):
+    """fp32 packed weight for this step (weights change every step: no caching)."""
+    return _ops.pack_linear(w, b, dtype=F32)
+
+
+def _ln(mod: nn.Module, what: str):
+    p = layernorm_params(mod, what)
+    if p is None:
+        return None
+    return _ops.f32vec(p[0]), _ops.f32vec(p[1]), p[2], p[0], p[1]   # (w32, b32, eps, weight Parameter, bias Parameter)
+
+
+def supported(model) -> Optional[str]:
+    """None when the training path can run this model, else the reason."""
+    vt = getattr(model, "vit_model", None)
+    if not isinstance(vt, VisionTransformer):
+        return "VITC.vit_model must be this package's VisionTransformer"
+    if not isinstance(vt.patch_embed, PatchEmbed) or not vt.patch_embed.flatten:
+        return "patch embedding must be this package's PatchEmbed(flatten=True)"
+    if vt.pos_embed is None:
+        return "a learnable position embedding is required"
+    for blk in vt.blocks:
+        if type(blk) is not Block:
+            return f"block type {type(blk).__name__} has no backward yet"
+        if blk.attn.qk_norm or blk.mlp.use_conv:
+            return "Attention(qk_norm=True) / MLP(use_conv=True) have no backward yet"
+    return None
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# forward that keeps what the backward needs
+# ----------------------------------------------------------------------------------------------------------------
+def _block_forward(blk: Block, x: torch.Tensor, B: int, N: int) -> (torch.Tensor, dict):
+    D, M, dev = blk.dim, B * N, x.device
+    attn, mlp = blk.attn, blk.mlp
+    attn._check()
+    _check_gelu(mlp.ac1, "MLP")
+    H, hd, hid = attn.num_heads, attn.head_dim, mlp.hidden_features
+    ln1, ln2 = _ln(blk.norm1, "Block.norm1"), _ln(blk.norm2, "Block.norm2")
+    s = {"x": x}
+    n1 = x
+    if ln1 is not None:
+        n1 = _buf(M, D, dev)
+        _ops.layernorm(x, n1, M, D, ln1[0], ln1[1], ln1[2])
+    qkv = torch.empty((M, 3 * D), dtype=F32, device=dev)
+    _ops.gemm(n1, _pk(attn.qkv.weight, attn.qkv.bias), qkv, _ops.EPI_BIAS, M)
+    o = _buf(M, D, dev)
+    lse = torch.empty(B * H * N, dtype=F32, device=dev)
+    T.attention_lse(qkv, o, lse, B, N, H, hd, attn.scale)
+    z1 = torch.empty((M, _ops.round_up(D, 8)), dtype=F32, device=dev)
+    _ops.gemm(o, _pk(attn.proj.weight, attn.proj.bias), z1, _ops.EPI_BIAS, M)
+    x1 = _buf(M, D, dev)
+    T.residual_scale(x, z1, _ops.f32vec(blk.ls1.gamma), x1, M, D)
+    n2 = x1
+    if ln2 is not None:
+        n2 = n1 if ln1 is not None else _buf(M, D, dev)       # reuse the scratch
+        _ops.layernorm(x1, n2, M, D, ln2[0], ln2[1], ln2[2])
+    pre = _buf(M, hid, dev)
+    p1 = _pk(mlp.linear_layer1.weight, mlp.linear_layer1.bias)
+    _ops.gemm(n2, p1, pre, _ops.EPI_BIAS, M)
+    h = _buf(M, hid, dev)
+    _ops.gelu(pre, h, M, _ops.round_up(hid, 8))
+    z2 = torch.empty((M, _ops.round_up(D, 8)), dtype=F32, device=dev)
+    _ops.gemm(h, _pk(mlp.linear_layer2.weight, mlp.linear_layer2.bias), z2, _ops.EPI_BIAS, M)
+    x2 = _buf(M, D, dev)
+    T.residual_scale(x1, z2, _ops.f32vec(blk.ls2.gamma), x2, M, D)
+    s.update(qkv=qkv, o=o, lse=lse, z1=z1, x1=x1, pre=pre, z2=z2)
+    return x2, s
+
+
+def forward_train(model, img: torch.Tensor):
+    """(logits [B, C], saved state) -- the fp32 forward of VITC with the activations of the backward kept."""
+    vt: VisionTransformer = model.vit_model
+    pe: PatchEmbed = vt.patch_embed
+    dev = img.device
+    B, Cin, Himg, Wimg = img.shape
+    assert pe.image_size[0] == Himg, "Input tensor's height does not match the model"
+    assert pe.image_size[1] == Wimg, "Input tensor's width does not match the model"
+    D, Np = vt.embed_dim, pe.num_patches
+    has_cls = vt.class_token is not None
+    N = Np + (1 if has_cls else 0)
+    M = B * N
+    if D % 8 != 0:
+        raise NotImplementedError("the training path needs embed_dim % 8 == 0")
+    f = _ops.f32vec
+    S = {"B": B, "N": N, "M": M, "D": D, "has_cls": has_cls}
+
+    pk_pe = _pk(pe.projection.weight, pe.projection.bias)
+    A = torch.empty((M, pk_pe.kpad), dtype=F32, device=dev)
+    _ops.im2col(img.contiguous(), A, pe.patch_size, pk_pe.kpad, has_cls)       # class-token rows are zero rows
+    x = _buf(M, D, dev)
+    _ops.gemm(A, pk_pe, x, _ops.EPI_BIAS, M)
+    S["A"] = A
+    en = _ln(pe.norm_layer, "PatchEmbed.norm_layer")
+    npre = _ln(vt.norm_pre, "VisionTransformer.norm_pre")
+    S["tok"] = x.clone() if en is not None else None
+    cls = f(vt.class_token.reshape(-1)) if has_cls else None
+    if en is not None or has_cls:
+        _ops.embed_finalize(x, B, N, D, cls, None, en[0] if en else None, en[1] if en else None, en[2] if en else 0.0,
+                            None, None, 0.0)
+    S["xcat"] = x.clone() if npre is not None else None
+    _ops.embed_finalize(x, B, N, D, None, f(vt.pos_embed.reshape(N, D)), None, None, 0.0,
+                        npre[0] if npre else None, npre[1] if npre else None, npre[2] if npre else 0.0)
+    S["blocks"] = []
+    for blk in vt.blocks:
+        x, s = _block_forward(blk, x, B, N)
+        S["blocks"].append(s)
+    S["xL"] = x
+    ld = x.shape[1]
+    xc = x.view(B, N, ld)[:, 0]                           # class-token rows, row stride N * ld
+    fin = _ln(vt.norm_final, "VisionTransformer.norm_final")
+    nf = xc
+    if fin is not None:
+        nf = _buf(B, D, dev)
+        _ops.layernorm(xc, nf, B, D, fin[0], fin[1], fin[2])
+    S["nf"] = nf
+    pk_h = _pk(model.head.weight, model.head.bias)
+    logits = torch.empty((B, pk_h.npad), dtype=F32, device=dev)
+    _ops.gemm(nf, pk_h, logits, _ops.EPI_BIAS, B)
+    return logits[:, :model.head.out_features], S
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# backward
+# ----------------------------------------------------------------------------------------------------------------
+def _linear_backward(G: Dict, lin: nn.Linear, dy: torch.Tensor, x_in: torch.Tensor, M: int, need_dx: bool = True):
+    """Gradients of y = x W^T + b: G[weight], G[bias]; returns dx [M, >= in_features] (or None)."""
+    N, K = lin.weight.shape
+    G[lin.weight] = T.linear_dw(dy, x_in, M, N, K)
+    if lin.bias is not None:
+        G[lin.bias] = T.colsum(dy, M, N)
+    return T.linear_dx(dy, lin.weight, M) if need_dx else None
+
+
+def _block_backward(G: Dict, blk: Block, s: dict, dx2: torch.Tensor, B: int, N: int) -> torch.Tensor:
+    D, M, dev = blk.dim, B * N, dx2.device
+    attn, mlp = blk.attn, blk.mlp
+    H, hd, hid = attn.num_heads, attn.head_dim, mlp.hidden_features
+    ln1, ln2 = _ln(blk.norm1, "Block.norm1"), _ln(blk.norm2, "Block.norm2")
+    g1, g2 = _ops.f32vec(blk.ls1.gamma), _ops.f32vec(blk.ls2.gamma)
+
+    # ---- MLP branch: x2 = x1 + g2 * z2, z2 = fc2(gelu(pre)), pre = fc1(LN2(x1))
+    G[blk.ls2.gamma] = T.colsum(dx2, M, D, s["z2"])
+    dz2 = torch.empty((M, _ops.round_up(D, 8)), dtype=F32, device=dev)
+    _ops.scale_channels(dx2[:, :dz2.shape[1]] if dx2.shape[1] != dz2.shape[1] else dx2, dz2, M, _ops.round_up(D, 8), _pad8(g2))
+    h = _buf(M, hid, dev)
+    _ops.gelu(s["pre"], h, M, _ops.round_up(hid, 8))
+    dh = _linear_backward(G, mlp.linear_layer2, dz2, h, M)
+    dpre = h                                              # reuse: h is dead after the weight gradient
+    T.gelu_bwd(s["pre"], dh, dpre, M, hid)
+    n2 = s["x1"]
+    if ln2 is not None:
+        n2 = _buf(M, D, dev)
+        _ops.layernorm(s["x1"], n2, M, D, ln2[0], ln2[1], ln2[2])
+    dn2 = _linear_backward(G, mlp.linear_layer1, dpre, n2, M)
+    dx1 = _buf(M, D, dev)
+    if ln2 is not None:
+        G[ln2[3]] = torch.empty(D, dtype=F32, device=dev)
+        G[ln2[4]] = torch.empty(D, dtype=F32, device=dev)
+        T.layernorm_bwd(s["x1"], dn2, ln2[0], ln2[2], M, D, dx1, dx_add=dx2, dw_out=G[ln2[3]], db_out=G[ln2[4]])
+    else:
+        _add(dx2, dn2, dx1, M, D)
+
+    # ---- attention branch: x1 = x + g1 * z1, z1 = proj(attn(qkv)), qkv = Wqkv LN1(x)
+    G[blk.ls1.gamma] = T.colsum(dx1, M, D, s["z1"])
+    dz1 = dz2
+    _ops.scale_channels(dx1[:, :dz1.shape[1]] if dx1.shape[1] != dz1.shape[1] else dx1, dz1, M, _ops.round_up(D, 8), _pad8(g1))
+    d_o = _linear_backward(G, attn.proj, dz1, s["o"], M)
+    dqkv = torch.empty((M, 3 * D), dtype=F32, device=dev)
+    T.attention_bwd(s["qkv"], s["o"], d_o, s["lse"], dqkv, B, N, H, hd, attn.scale)
+    n1 = s["x"]
+    if ln1 is not None:
+        n1 = n2 if ln2 is not None else _buf(M, D, dev)
+        _ops.layernorm(s["x"], n1, M, D, ln1[0], ln1[1], ln1[2])
+    dn1 = _linear_backward(G, attn.qkv, dqkv, n1, M)
+    dx = _buf(M, D, dev)
+    if ln1 is not None:
+        G[ln1[3]] = torch.empty(D, dtype=F32, device=dev)
+        G[ln1[4]] = torch.empty(D, dtype=F32, device=dev)
+        T.layernorm_bwd(s["x"], dn1, ln1[0], ln1[2], M, D, dx, dx_add=dx1, dw_out=G[ln1[3]], db_out=G[ln1[4]])
+    else:
+        _add(dx1, dn1, dx, M, D)
+    return dx
+
+
+def _pad8(v: torch.Tensor) -> torch.Tensor:
+    n = v.numel()
+    n8 = _ops.round_up(n, 8)
+    if n8 == n:
+        return v
+    out = torch.zeros(n8, dtype=F32, device=v.device)
+    out[:n] = v
+    return out
+
+
+def _add(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, M: int, D: int) -> None:
+    """out = a + b over [M, D] (residual_scale with a unit LayerScale)."""
+    ones = torch.ones(D, dtype=F32, device=a.device)
+    T.residual_scale(a, b, ones, out, M, D)
+
+
+def backward_train(model, S: dict, dlogits: torch.Tensor) -> Dict[nn.Parameter, torch.Tensor]:
+    """Gradients of every parameter given d(loss)/d(logits) [B, C]."""
+    vt: VisionTransformer = model.vit_model
+    pe: PatchEmbed = vt.patch_embed
+    B, N, M, D, has_cls = S["B"], S["N"], S["M"], S["D"], S["has_cls"]
+    dev = dlogits.device
+    G: Dict[nn.Parameter, torch.Tensor] = {}
+    C = model.head.out_features
+    dl = dlogits.contiguous()
+
+    # ---- head and final norm (class-token rows only)
+    dnf = _linear_backward(G, model.head, dl, S["nf"], B)
+    xL = S["xL"]
+    ld = xL.shape[1]
+    dx = torch.zeros((M, ld), dtype=F32, device=dev)
+    dxc = dx.view(B, N, ld)[:, 0]                          # gradient lands in the class-token rows
+    fin = _ln(vt.norm_final, "VisionTransformer.norm_final")
+    if fin is not None:
+        G[fin[3]] = torch.empty(D, dtype=F32, device=dev)
+        G[fin[4]] = torch.empty(D, dtype=F32, device=dev)
+        T.layernorm_bwd(xL.view(B, N, ld)[:, 0], dnf, fin[0], fin[2], B, D, dxc, dw_out=G[fin[3]], db_out=G[fin[4]])
+    else:
+        dxc.copy_(dnf[:, :ld] if dnf.shape[1] >= ld else torch.nn.functional.pad(dnf, (0, ld - dnf.shape[1])))
+
+    # ---- blocks, last to first
+    for blk, s in zip(reversed(list(vt.blocks)), reversed(S["blocks"])):
+        dx = _block_backward(G, blk, s, dx, B, N)
+
+    # ---- x0 = LN_pre(xcat) + pos ; xcat = [cls ; LN_e(tok)] ; tok = im2col(img) Wpe^T (+ b)
+    dpos = T.colsum(dx.view(B, N * ld), B, N * ld)         # sum over the batch
+    G[vt.pos_embed] = dpos.view(N, ld)[:, :D].reshape(1, N, D)
+    npre = _ln(vt.norm_pre, "VisionTransformer.norm_pre")
+    dxcat = dx
+    if npre is not None:
+        dxcat = _buf(M, D, dev)
+        G[npre[3]] = torch.empty(D, dtype=F32, device=dev)
+        G[npre[4]] = torch.empty(D, dtype=F32, device=dev)
+        T.layernorm_bwd(S["xcat"], dx, npre[0], npre[2], M, D, dxcat, dw_out=G[npre[3]], db_out=G[npre[4]])
+    if has_cls:
+        G[vt.class_token] = T.colsum(dxcat.view(B, N * ld), B, D).reshape(1, 1, D)
+        dxcat.view(B, N, ld)[:, 0].zero_()                 # the class-token rows carry no patch gradient
+    en = _ln(pe.norm_layer, "PatchEmbed.norm_layer")
+    dtok = dxcat
+    if en is not None:
+        dtok = _buf(M, D, dev)
+        G[en[3]] = torch.empty(D, dtype=F32, device=dev)
+        G[en[4]] = torch.empty(D, dtype=F32, device=dev)
+        T.layernorm_bwd(S["tok"], dxcat, en[0], en[2], M, D, dtok, dw_out=G[en[3]], db_out=G[en[4]])
+        if has_cls:
+            dtok.view(B, N, ld)[:, 0].zero_()
+    Wpe = pe.projection.weight
+    Dp, Kp = Wpe.shape[0], Wpe[0].numel()
+    G[Wpe] = T.linear_dw(dtok, S["A"], M, Dp, Kp).reshape(Wpe.shape)
+    if pe.projection.bias is not None:
+        G[pe.projection.bias] = T.colsum(dtok, M, Dp)
+    return G
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# autograd hook-up
+# ----------------------------------------------------------------------------------------------------------------
+class _VitcFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, model, img, *params):
+        with torch.cuda.device(img.device):
+            logits, S = forward_train(model, img)
+        ctx.model, ctx.S, ctx.params = model, S, params
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        with torch.cuda.device(dlogits.device):
+            G = backward_train(ctx.model, ctx.S, dlogits)
+        ctx.S = None
+        return (None, None) + tuple(G.get(p).reshape(p.shape) if G.get(p) is not None else None for p in ctx.params)
+
+
+def vitc_forward_with_grad(model, img: torch.Tensor) -> torch.Tensor:
+    """``model(img)`` with an autograd graph: logits whose ``backward`` fills every parameter's ``.grad``."""
+    why = supported(model)
+    if why is not None:
+        raise NotImplementedError(f"training path: {why}")
+    if img.dtype != F32:
+        raise TypeError("the training path is fp32 (the reference trains in fp32): pass fp32 images")
+    params = [p for p in model.parameters()]
+    if any(p.dtype != F32 for p in params):
+        raise TypeError("the training path needs fp32 parameters")
+    return _VitcFunction.apply(model, img, *params)
+
+
+class _CrossEntropyFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, labels):
+        with torch.cuda.device(logits.device):
+            loss, dl = T.cross_entropy(logits.contiguous(), labels, want_grad=True)
+        ctx.save_for_backward(dl)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        (dl,) = ctx.saved_tensors
+        return dl * g, None      # g is the scalar 1 of loss.backward(); a torch multiply of a [B, C] tensor by it
+
+
+class CrossEntropyLoss(nn.Module):
+    """``nn.CrossEntropyLoss()`` with class-index targets and mean reduction (train.py:187), as a HIP kernel."""
+
+    def forward(self, logits: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
+        _ops.require_cuda(logits, "CrossEntropyLoss.forward")
+        if logits.dtype != F32 or logits.dim() != 2:
+            raise TypeError("CrossEntropyLoss expects fp32 logits of shape (B, C)")
+        return _CrossEntropyFunction.apply(logits, labels)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# gradients in one flat buffer, clipping, AdamW, data-parallel all-reduce
+# ----------------------------------------------------------------------------------------------------------------
+class FlatGradients:
+    """Every parameter's ``.grad`` as a view into one flat fp32 buffer: one kernel clips them all, one collective
+    all-reduces them all.  ``zero()`` replaces ``optimizer.zero_grad()``."""
+
+    def __init__(self, params):
+        self.params = [p for p in params if p.requires_grad]
+        total = sum(p.numel() for p in self.params)
+        dev = self.params[0].device
+        self.flat = torch.zeros(total, dtype=F32, device=dev)
+        off = 0
+        for p in self.params:
+            p.grad = self.flat[off:off + p.numel()].view(p.shape)
+            off += p.numel()
+
+    def zero(self) -> None:
+        self.flat.zero_()
+        off = 0
+        for p in self.params:                  # re-attach views that zero_grad(set_to_none=True) may have dropped
+            if p.grad is None or p.grad.data_ptr() != self.flat.data_ptr() + 4 * off:
+                p.grad = self.flat[off:off + p.numel()].view(p.shape)
+            off += p.numel()
+
+    def clip_grad_norm_(self, max_norm: float) -> torch.Tensor:
+        """torch.nn.utils.clip_grad_norm_ (train.py:222): returns the total norm (a device scalar)."""
+        with torch.cuda.device(self.flat.device):
+            return T.grad_clip(self.flat, max_norm)[0]
+
+    def all_reduce(self, group=None) -> None:
+        """Average the gradients over the data-parallel group (RCCL over xGMI when the backend is nccl)."""
+        import torch.distributed as dist
+        if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+            return
+        if dist.get_backend(group) == "nccl":
+            dist.all_reduce(self.flat, op=dist.ReduceOp.AVG, group=group)
+        else:                                   # gloo rehearsal on CPU tensors: sum, then divide
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
+            self.flat.div_(dist.get_world_size(group))
+
+
+class AdamW(torch.optim.Optimizer):
+    """torch.optim.AdamW (train.py:68-72) with the update in a HIP kernel; state_dict layout is torch's, so optimizer
+    states saved by the reference load and the torch LR schedulers drive it."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = closure() if closure is not None else None
+        for group in self.param_groups:
+            b1, b2 = group["betas"]
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                if not p.is_cuda or p.dtype != F32 or not p.is_contiguous() or not p.grad.is_contiguous():
+                    raise RuntimeError("vitm_amd AdamW updates contiguous fp32 CUDA parameters")
+                st = self.state[p]
+                if len(st) == 0:
+                    st["step"] = torch.tensor(0.0)
+                    st["exp_avg"] = torch.zeros_like(p)
+                    st["exp_avg_sq"] = torch.zeros_like(p)
+                st["step"] += 1
+                with torch.cuda.device(p.device):
+                    T.adamw(p, p.grad, st["exp_avg"], st["exp_avg_sq"], group["lr"], b1, b2, group["eps"],
+                            group["weight_decay"], int(st["step"].item()))
+                torch.autograd.graph.increment_version(p)   # the kernel wrote p: cached packed weights must be rebuilt
+        return loss
+
+
+def reference_optimizer_and_scheduler(model, total_iters: int):
+    """The optimizer / scheduler of the reference's ``getOptimizerAndSchedular`` (train.py:65-93)."""
+    opt = AdamW(model.parameters(), lr=1e-3, weight_decay=0.05, betas=(0.9, 0.98))
+    sched = torch.optim.lr_scheduler.SequentialLR(
+        opt, [torch.optim.lr_scheduler.LinearLR(opt, start_factor=0.01, end_factor=1.0, total_iters=500),
+              torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=max(1, total_iters - 500), eta_min=1e-6)],
+        milestones=[500])
+    return opt, sched
+
+
+class Trainer:
+    """One object for the loop body of train.py:215-224 (plus the data-parallel all-reduce)."""
+
+    def __init__(self, model, optimizer, scheduler=None, max_norm: float = 1.0, group=None):
+        self.model, self.optimizer, self.scheduler, self.max_norm, self.group = model, optimizer, scheduler, max_norm, group
+        self.grads = FlatGradients(model.parameters())
+        self.criterion = CrossEntropyLoss()
+        self.last_grad_norm = None
+
+    def step(self, images: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
+        self.grads.zero()
+        logits = vitc_forward_with_grad(self.model, images)
+        loss = self.criterion(logits, labels)
+        loss.backward()
+        self.grads.all_reduce(self.group)
+        self.last_grad_norm = self.grads.clip_grad_norm_(self.max_norm)
+        self.optimizer.step()
+        if self.scheduler is not None:
+            self.scheduler.step()
+        return loss.detach()
