@@ -112,6 +112,56 @@ def fc1_kernel_time(model, x, steps):
     return sum(ms) / len(ms), len(ms)
 
 
+def train_bench(args, world, rank, dist, dev):
+    """Informational: images/sec of the fp32 training step (the reference trains in fp32), data-parallel over the ranks
+    with the gradient all-reduce on RCCL.  Not the headline metric."""
+    from oracle.vit_oracle import flops_per_image
+    from vitm_amd import training
+    from vitm_amd.sharding import max_over_ranks
+    cfg = W.CONFIGS[args.config]
+    shp = W.shapes(cfg)
+    model, _ = build_model(cfg, dev)
+    model = model.float().train()
+    opt, sched = training.reference_optimizer_and_scheduler(model, 100000)
+    tr = training.Trainer(model, opt, sched, max_norm=1.0)
+    g = torch.Generator(device="cpu").manual_seed(4321 + rank)
+    x = (torch.rand((args.batch, 3, cfg["image_size"], cfg["image_size"]), generator=g) * 2 - 1).to(dev)
+    y = torch.randint(0, cfg["num_classes"], (args.batch,), generator=g).to(dev)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        tr.step(x, y)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = tr.step(x, y)
+    barrier()
+    elapsed = max_over_ranks(time.perf_counter() - t0, dist, dev)
+    assert torch.isfinite(loss).all()
+    if rank == 0:
+        value = world * args.batch * args.steps / elapsed
+        tf = value / world * 3.0 * flops_per_image(shp) / 1e12      # backward = 2x forward
+        print(json.dumps({
+            "metric": f"images/sec, {args.config} fp32 training step", "value": round(value, 1), "unit": "images/sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.config}: forward + cross-entropy + backward + gradient all-reduce + clip + AdamW",
+                       "batch_per_gpu": args.batch, "global_batch": args.batch * world,
+                       "parallelism": f"data parallel x{world}, one flat-gradient all-reduce (RCCL) per step"},
+            "roofline": {"bound": "mfma", "achieved": round(tf, 1), "peak": 157.0, "unit": "TFLOP/s",
+                         "frac": round(tf / 157.0, 4), "traffic": None,
+                         "kernel": "whole step against the fp32 MFMA peak (3 x forward FLOPs)"},
+            "final_loss": round(float(loss), 4)}), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -121,6 +171,8 @@ def main():
     ap.add_argument("--config", default="vit_b16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", action="store_true", help="replay the forward from a HIP graph (same kernels, one host call)")
+    ap.add_argument("--mode", default="forward", choices=["forward", "train"],
+                    help="train: one fp32 training step per step (forward, loss, backward, all-reduce, clip, AdamW)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -136,6 +188,8 @@ def main():
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
+    if args.mode == "train":
+        return train_bench(args, world, rank, dist, dev)
     cfg = W.CONFIGS[args.config]
     shp = W.shapes(cfg)
     from oracle.vit_oracle import flops_per_image
