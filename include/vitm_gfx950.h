@@ -200,8 +200,9 @@ int vitm_cast_f32_to_bf16(const float* src, void* dst, int64_t n, vitm_stream_t 
 int vitm_cast_bf16_to_f32(const void* src, float* dst, int64_t n, vitm_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------
- * Training step, fp32 (the reference trains in fp32: vitm/training/train.py:208-241).  The GEMMs of the
- * backward pass are vitm_gemm_f32 calls on transposed operands; the entry points below are the rest.
+ * Training step (vitm/training/train.py:208-241).  The GEMMs of the backward pass are vitm_gemm / vitm_gemm_f32
+ * calls on transposed operands; the entry points below are the rest.  Activation-sized operands are fp32 (the
+ * reference's training precision) or bf16 (`dtype`: mixed precision, fp32 statistics and reductions).
  * ------------------------------------------------------------------------------------------------------ */
 
 /*
@@ -210,6 +211,10 @@ int vitm_cast_bf16_to_f32(const void* src, float* dst, int64_t n, vitm_stream_t 
  */
 int vitm_attention_f32_lse(const float* qkv, int64_t ldqkv, float* out, int64_t ldo, float* lse, int B, int N,
                            int H, int head_dim, float scale, vitm_stream_t stream);
+
+/* vitm_attention (bf16) that also writes the same lse array (mixed-precision training forward). */
+int vitm_attention_lse(const void* qkv, int64_t ldqkv, void* out, int64_t ldo, float* lse, int B, int N, int H,
+                       int head_dim, float scale, vitm_stream_t stream);
 
 /*
  * Backward of models.py:88-93: dqkv (B*N, 3*D; [dq | dk | dv], every element written) from qkv, the forward
@@ -220,33 +225,34 @@ int vitm_attention_bwd_f32(const float* qkv, int64_t ldqkv, const float* o, int6
                            int H, int head_dim, float scale, vitm_stream_t stream);
 
 /* dst[n, m] = src[m, n] for m < M, zero for M <= m < m_pad (K padding of the weight-gradient GEMM's operands). */
-int vitm_transpose_f32(const float* src, int64_t lds, float* dst, int64_t ldd, int M, int N, int m_pad,
-                       vitm_stream_t stream);
+int vitm_transpose(const void* src, int64_t lds, void* dst, int64_t ldd, int dtype, int M, int N, int m_pad,
+                   vitm_stream_t stream);
 
 /*
  * out[c, d] = sum over the rows m of chunk c (nchunks equal chunks of the M rows) of a[m, d] * (b ? b[m, d] : 1).
  * Bias gradients (b = NULL), LayerScale gradients (a = d_y, b = branch output), second stage of LayerNorm
- * parameter gradients.  Call once with nchunks > 1 into a partial array, then once with nchunks = 1 over it.
+ * parameter gradients.  a and b are in `dtype`, out is fp32.  Call once with nchunks > 1 into a partial array, then
+ * once (dtype fp32) with nchunks = 1 over it.
  */
-int vitm_colsum_f32(const float* a, int64_t lda, const float* b, int64_t ldb, float* out, int64_t ldo, int M,
-                    int D, int nchunks, vitm_stream_t stream);
+int vitm_colsum(const void* a, int64_t lda, const void* b, int64_t ldb, int dtype, float* out, int64_t ldo, int M,
+                int D, int nchunks, vitm_stream_t stream);
 
 /*
  * LayerNorm backward: dx[m,:] = (dx_add ? dx_add[m,:] : 0) + rstd * (g - mean(g) - xhat * mean(g * xhat)), g = dy * w;
- * dw_partial / db_partial are (nblocks, D) per-workgroup sums of dy * xhat / dy (reduce them with vitm_colsum_f32).
- * Backward of nn.LayerNorm (models.py:189,196,310,324).
+ * dw_partial / db_partial are (nblocks, D) fp32 per-workgroup sums of dy * xhat / dy (reduce them with vitm_colsum);
+ * x, dy, dx_add and dx are in `dtype`.  Backward of nn.LayerNorm (models.py:189,196,310,324).
  */
-int vitm_layernorm_bwd_f32(const float* x, int64_t ldx, const float* dy, int64_t lddy, const float* w, float eps,
-                           const float* dx_add, int64_t ldadd, float* dx, int64_t lddx, float* dw_partial,
-                           float* db_partial, int nblocks, int M, int D, vitm_stream_t stream);
+int vitm_layernorm_bwd(const void* x, int64_t ldx, const void* dy, int64_t lddy, const float* w, float eps,
+                       const void* dx_add, int64_t ldadd, void* dx, int64_t lddx, int dtype, float* dw_partial,
+                       float* db_partial, int nblocks, int M, int D, vitm_stream_t stream);
 
 /* out[m,d] = resid[m,d] + gamma[d] * z[m,d]: LayerScale + residual add with the branch output kept (models.py:209-210). */
-int vitm_residual_scale_f32(const float* resid, int64_t ldr, const float* z, int64_t ldz, const float* gamma, float* out,
-                            int64_t ldo, int M, int D, vitm_stream_t stream);
+int vitm_residual_scale(const void* resid, int64_t ldr, const void* z, int64_t ldz, const float* gamma, void* out,
+                        int64_t ldo, int dtype, int M, int D, vitm_stream_t stream);
 
 /* dpre = dh * d/dx gelu_erf(pre): backward of nn.GELU() (models.py:128). */
-int vitm_gelu_bwd_f32(const float* pre, int64_t ldp, const float* dh, int64_t ldh, float* dpre, int64_t ldd, int M,
-                      int D, vitm_stream_t stream);
+int vitm_gelu_bwd(const void* pre, int64_t ldp, const void* dh, int64_t ldh, void* dpre, int64_t ldd, int dtype, int M,
+                  int D, vitm_stream_t stream);
 
 /*
  * loss[0] = mean over the batch of softmax cross-entropy(logits[b,:], labels[b]); dlogits (optional) its gradient.

@@ -138,3 +138,93 @@ def test_attention_backward(T, B, N, H, hd):
     T.attention_bwd(qkv, o, d_o, lse, dqkv, B, N, H, hd, hd ** -0.5)
     for name, sl in (("dq", slice(0, D)), ("dk", slice(D, 2 * D)), ("dv", slice(2 * D, 3 * D))):
         assert _rel(dqkv[:, sl], q64.grad[:, sl]) <= 1e-4, name
+
+
+# ---- bf16 variants (mixed-precision training): inputs are bf16-exact, so the only error is the rounding of the stored
+# ---- result (2^-9 relative) plus fp32 summation; bars are 1e-2 of the largest entry for bf16 outputs, 1e-4 for fp32 ones
+BF = torch.bfloat16
+
+
+def test_transpose_bf16(T):
+    M, N, mp = 333, 200, 384
+    src = _rand(M, N + 8, seed=31).to(BF)[:, :N]
+    dst = T.transpose(src, M, N, mp)
+    assert dst.dtype == BF and torch.equal(dst[:, :M], src.t()) and (dst[:, M:] == 0).all()
+
+
+def test_colsum_bf16(T):
+    M, D = 3000, 200
+    a, b = _rand(M, D, seed=32).to(BF), _rand(M, D, seed=33).to(BF)
+    got = T.colsum(a, M, D, b)
+    assert got.dtype == torch.float32
+    assert _rel(got, (a.double() * b.double()).sum(0)) <= 1e-5
+    assert _rel(T.colsum(a, M, D), a.double().sum(0)) <= 1e-5
+
+
+def test_layernorm_bwd_bf16(T):
+    M, D = 500, 192
+    x = (_rand(M, D, seed=34) * 2 + 0.5).to(BF)
+    dy, add = _rand(M, D, seed=35).to(BF), _rand(M, D, seed=36).to(BF)
+    w = (1 + 0.2 * _rand(D, seed=37))
+    x64 = x.double().requires_grad_(True)
+    w64 = w.double().requires_grad_(True)
+    b64 = torch.zeros(D, device=DEV, dtype=torch.float64, requires_grad=True)
+    F.layer_norm(x64, (D,), w64, b64, 1e-5).backward(dy.double())
+    dx = torch.empty((M, D), device=DEV, dtype=BF)
+    dw, db = torch.empty(D, device=DEV), torch.empty(D, device=DEV)
+    T.layernorm_bwd(x, dy, w, 1e-5, M, D, dx, dx_add=add, dw_out=dw, db_out=db)
+    assert _rel(dx, x64.grad + add.double()) <= 1e-2
+    assert _rel(dw, w64.grad) <= 1e-4 and _rel(db, b64.grad) <= 1e-4
+
+
+def test_gelu_bwd_and_residual_scale_bf16(T):
+    M, D = 300, 200
+    pre = (_rand(M, D, seed=38) * 2).to(BF)
+    dh = _rand(M, D, seed=39).to(BF)
+    p64 = pre.double().requires_grad_(True)
+    F.gelu(p64).backward(dh.double())
+    out = torch.empty((M, D), device=DEV, dtype=BF)
+    T.gelu_bwd(pre, dh, out, M, D)
+    assert _rel(out, p64.grad) <= 1e-2
+    g = 1 + 0.1 * _rand(D, seed=40)
+    T.residual_scale(pre, dh, g, out, M, D)
+    assert _rel(out, pre.double() + g.double() * dh.double()) <= 1e-2
+
+
+@pytest.mark.parametrize("M,N,K", [(200, 136, 128), (197 * 3, 768, 192), (65, 10, 192)])
+def test_linear_backward_bf16(T, M, N, K):
+    x = _rand(M, K, seed=41).to(BF)
+    w = (_rand(N, K, seed=42) * K ** -0.5).to(BF).float()          # fp32 master weight holding bf16-exact values
+    dy = _rand(M, N, seed=43).to(BF)
+    x64, w64 = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    (x64 @ w64.t()).backward(dy.double())
+    dx = T.linear_dx(dy, w, M)
+    assert dx.dtype == BF and _rel(dx[:, :K], x64.grad) <= 1e-2
+    dw = T.linear_dw(dy, x, M, N, K)
+    assert dw.dtype == torch.float32 and _rel(dw, w64.grad) <= 1e-4   # fp32 accumulators stored as fp32
+
+
+@pytest.mark.parametrize("B,N,H,hd", [(2, 65, 3, 64), (1, 197, 2, 64), (2, 50, 2, 96), (1, 33, 2, 32), (1, 100, 1, 128),
+                                      (1, 300, 1, 64), (2, 1, 2, 64)])
+def test_attention_backward_bf16(T, B, N, H, hd):
+    from vitm_amd import _ops
+    D = H * hd
+    qkv = (_rand(B * N, 3 * D, seed=44) * 1.2).to(BF)
+    d_o = _rand(B * N, D, seed=45).to(BF)
+    q64 = qkv.double().requires_grad_(True)
+    q, k, v = q64.reshape(B, N, 3, H, hd).permute(2, 0, 3, 1, 4)
+    s = (q * hd ** -0.5) @ k.transpose(-2, -1)
+    ref_o = (s.softmax(-1) @ v).transpose(1, 2).reshape(B * N, D)
+    ref_o.backward(d_o.double())
+    o = torch.empty((B * N, D), device=DEV, dtype=BF)
+    lse = torch.full((B * H * N,), float("nan"), device=DEV)
+    T.attention_lse(qkv, o, lse, B, N, H, hd, hd ** -0.5)
+    o2 = torch.empty_like(o)
+    _ops.attention(qkv, o2, B, N, H, hd, hd ** -0.5)
+    assert torch.equal(o, o2), "the lse variant computes the same output"
+    ref_lse = (torch.logsumexp(s.detach(), -1) * 1.4426950408889634).reshape(-1)      # log2 domain, (b, h, n)
+    assert (lse.double() - ref_lse).abs().max().item() <= 1e-3
+    dqkv = torch.full((B * N, 3 * D), float("nan"), device=DEV, dtype=BF)
+    T.attention_bwd(qkv, o, d_o, lse, dqkv, B, N, H, hd, hd ** -0.5)
+    for name, sl in (("dq", slice(0, D)), ("dk", slice(D, 2 * D)), ("dv", slice(2 * D, 3 * D))):
+        assert _rel(dqkv[:, sl], q64.grad[:, sl]) <= 2e-2, name

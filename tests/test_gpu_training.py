@@ -109,3 +109,77 @@ def test_inference_path_unchanged_under_no_grad():
     b = model(x)
     assert not a.requires_grad and b.requires_grad
     assert (a - b.detach()).abs().max().item() <= 1e-4 * a.abs().max().item()
+
+
+# ---- bf16 mixed precision -----------------------------------------------------------------------------------------
+# The reference has no bf16 training run to compare with (train.py has no autocast), so the bars are those of a
+# mixed-precision step against the reference's fp32 one: loss within 1e-2 relative, gradient norm within 3e-2, every
+# parameter gradient at cosine >= 0.99 to the reference's (0.95 for tensors of fewer than 1000 entries, where a few
+# rounded entries move the angle), parameters after three lr-sized AdamW steps within 1e-4 absolute and 1e-5 on average.
+def _cos(a, b):
+    a, b = a.double().flatten(), b.double().flatten()
+    return (a @ b / (a.norm() * b.norm()).clamp_min(1e-30)).item()
+
+
+def test_bf16_training_steps_track_reference():
+    from vitm_amd import training
+    g = np.load(os.path.join(GOLD, "train_tiny2.npz"))
+    cfg = W.CONFIGS["tiny2"]
+    seed, batch, steps = int(g["seed"]), int(g["batch"]), int(g["steps"])
+    model = _model(cfg, seed)
+    opt, sched = training.reference_optimizer_and_scheduler(model, 1000)
+    tr = training.Trainer(model, opt, sched, max_norm=1.0, compute_dtype=torch.bfloat16)
+    for step in range(steps):
+        x = torch.from_numpy(W.make_input(cfg, batch, seed + 10 + step)).cuda()
+        y = torch.from_numpy(g[f"labels{step}"]).cuda()
+        if step == 0:
+            tr.grads.zero()
+            logits = model(x.to(torch.bfloat16))         # bf16 images select the mixed-precision path
+            assert logits.requires_grad and logits.dtype == torch.float32
+            loss = training.CrossEntropyLoss()(logits, y)
+            loss.backward()
+            assert abs(loss.item() - g["losses"][0]) <= 1e-2 * abs(g["losses"][0])
+            worst = 1.0
+            for k, p in model.named_parameters():
+                ref = torch.from_numpy(g["grad." + k])
+                assert p.grad is not None and p.grad.dtype == torch.float32 and torch.isfinite(p.grad).all(), k
+                c = _cos(p.grad.cpu(), ref)
+                worst = min(worst, c)
+                assert c >= (0.99 if ref.numel() >= 1000 else 0.95), f"{k}: gradient cosine {c:.4f}"
+            print("worst gradient cosine", worst)
+        loss = tr.step(x, y)                              # fp32 images, compute_dtype=bf16
+        assert abs(loss.item() - g["losses"][step]) <= 1e-2 * abs(g["losses"][step]), (step, loss.item())
+        assert abs(tr.last_grad_norm.item() - g["grad_norms"][step]) <= 3e-2 * g["grad_norms"][step], step
+    for k, p in model.named_parameters():
+        assert p.dtype == torch.float32
+        d = (p.detach().cpu() - torch.from_numpy(g["param." + k])).abs()
+        assert d.max().item() <= 1e-4 and d.mean().item() <= 1e-5, (k, d.max().item(), d.mean().item())
+
+
+def test_bf16_training_with_padding_tracks_float64(monkeypatch):
+    from oracle import vit_oracle as O
+    from vitm_amd import training
+    from vitm_amd.models import VisionTransformer, VITC
+    vt = VisionTransformer(32, patch_size=4, num_classes=10, num_heads=2, mlp_ratio=0.8, depth=2, embed_dim=192)
+    model = VITC(vt).train()
+    torch.manual_seed(3)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if n.endswith("gamma"):
+                p.copy_(1.0 + 0.1 * torch.randn_like(p))
+            elif n.endswith("bias"):
+                p.normal_(0, 0.1)
+    sd64 = {k: v.detach().double().requires_grad_(True) for k, v in model.state_dict().items()}
+    x = torch.randn(5, 3, 32, 32).to(torch.bfloat16)
+    y = torch.tensor([1, 0, 9, 3, 3])
+    ocfg = dict(image_size=(32, 32), patch_size=(4, 4), num_heads=2, depth=2)
+    monkeypatch.setattr(O, "_t", lambda sd, key, dtype: None if sd.get(key) is None else sd[key].to(dtype))
+    loss64 = torch.nn.functional.cross_entropy(O.vitc_forward(x.double(), sd64, ocfg, dtype=torch.float64), y)
+    loss64.backward()
+    model = model.cuda()
+    loss = training.CrossEntropyLoss()(model(x.cuda()), y.cuda())
+    loss.backward()
+    assert abs(loss.item() - loss64.item()) <= 1e-2 * abs(loss64.item())
+    for k, p in model.named_parameters():
+        c = _cos(p.grad.cpu(), sd64[k].grad)
+        assert c >= (0.99 if p.numel() >= 1000 else 0.95), f"{k}: {c:.4f}"

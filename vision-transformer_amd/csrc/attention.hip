@@ -32,7 +32,8 @@ __device__ __forceinline__ u16x4_t tr_read(const char* lds_addr) {
 template <int HD>
 __global__ __launch_bounds__(WAVES * 64) void attn_kernel(const bf16_t* __restrict__ qkv, int64_t ldq,
                                                           bf16_t* __restrict__ out, int64_t ldo, int N,
-                                                          int H, float sl2e, int kchunk, int nqg) {
+                                                          int H, float sl2e, int kchunk, int nqg,
+                                                          float* __restrict__ lse) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int RS = HD * 2 + 16;     // LDS row stride in bytes
   constexpr int CPR = HD / 8;         // 16-byte chunks per row
@@ -161,6 +162,8 @@ __global__ __launch_bounds__(WAVES * 64) void attn_kernel(const bf16_t* __restri
   if (!active) return;
   const float l = l_run + __shfl_xor(l_run, 32, 64);
   const float inv = 1.0f / l;
+  // log2-domain log-sum-exp of the scaled scores (training): p = exp2(s * scale * log2e - lse)
+  if (lse != nullptr && hh == 0 && q0 + r < N) lse[((int64_t)b * H + h) * N + q0 + r] = m_run * sl2e + __log2f(l);
   if (q0 + r < N) {
     bf16_t* op = out + ((int64_t)b * N + q0 + r) * ldo + h * HD;
 #pragma unroll
@@ -177,7 +180,7 @@ __global__ __launch_bounds__(WAVES * 64) void attn_kernel(const bf16_t* __restri
 
 template <int HD>
 int launch_attn(const void* qkv, int64_t ldq, void* out, int64_t ldo, int B, int N, int H, float scale,
-                hipStream_t st) {
+                float* lse, hipStream_t st) {
   const int npad = (N + KT - 1) / KT * KT;
   const int kchunk = npad < KCHUNK_MAX ? npad : KCHUNK_MAX;
   const int smem = 2 * kchunk * (HD * 2 + 16);
@@ -187,15 +190,15 @@ int launch_attn(const void* qkv, int64_t ldq, void* out, int64_t ldo, int B, int
   const int nqg = (nqb + WAVES - 1) / WAVES;
   dim3 grid((unsigned)((int64_t)nqg * B * H));
   hipLaunchKernelGGL(kfn, grid, dim3(WAVES * 64), smem, st, (const bf16_t*)qkv, ldq, (bf16_t*)out, ldo, N, H,
-                     scale * 1.4426950408889634f, kchunk, nqg);
+                     scale * 1.4426950408889634f, kchunk, nqg, lse);
   VITM_CHECK_LAUNCH("vitm_attention");
   return VITM_OK;
 }
 
 }  // namespace
 
-extern "C" int vitm_attention(const void* qkv, int64_t ldqkv, void* out, int64_t ldo, int B, int N, int H,
-                              int head_dim, float scale, vitm_stream_t stream) {
+static int attention_impl(const void* qkv, int64_t ldqkv, void* out, int64_t ldo, int B, int N, int H,
+                          int head_dim, float scale, float* lse, vitm_stream_t stream) {
   VITM_REQUIRE(qkv && out, "vitm_attention: null pointer");
   VITM_REQUIRE(B > 0 && N > 0 && H > 0, "vitm_attention: B, N, H must be positive");
   VITM_REQUIRE((int64_t)B * H * ((N + QB * WAVES - 1) / (QB * WAVES)) < (1ll << 31), "vitm_attention: grid too large for one launch");
@@ -206,12 +209,23 @@ extern "C" int vitm_attention(const void* qkv, int64_t ldqkv, void* out, int64_t
   VITM_REQUIRE(scale > 0.f, "vitm_attention: scale must be positive");
   hipStream_t st = (hipStream_t)stream;
   switch (head_dim) {
-    case 32: return launch_attn<32>(qkv, ldqkv, out, ldo, B, N, H, scale, st);
-    case 64: return launch_attn<64>(qkv, ldqkv, out, ldo, B, N, H, scale, st);
-    case 96: return launch_attn<96>(qkv, ldqkv, out, ldo, B, N, H, scale, st);
-    case 128: return launch_attn<128>(qkv, ldqkv, out, ldo, B, N, H, scale, st);
+    case 32: return launch_attn<32>(qkv, ldqkv, out, ldo, B, N, H, scale, lse, st);
+    case 64: return launch_attn<64>(qkv, ldqkv, out, ldo, B, N, H, scale, lse, st);
+    case 96: return launch_attn<96>(qkv, ldqkv, out, ldo, B, N, H, scale, lse, st);
+    case 128: return launch_attn<128>(qkv, ldqkv, out, ldo, B, N, H, scale, lse, st);
     default: break;
   }
   vitm_set_error("vitm_attention: head_dim=%d unsupported (32, 64, 96, 128)", head_dim);
   return VITM_EUNSUPPORTED;
+}
+
+extern "C" int vitm_attention(const void* qkv, int64_t ldqkv, void* out, int64_t ldo, int B, int N, int H,
+                              int head_dim, float scale, vitm_stream_t stream) {
+  return attention_impl(qkv, ldqkv, out, ldo, B, N, H, head_dim, scale, nullptr, stream);
+}
+
+extern "C" int vitm_attention_lse(const void* qkv, int64_t ldqkv, void* out, int64_t ldo, float* lse, int B, int N, int H,
+                                  int head_dim, float scale, vitm_stream_t stream) {
+  VITM_REQUIRE(lse, "vitm_attention_lse: null lse");
+  return attention_impl(qkv, ldqkv, out, ldo, B, N, H, head_dim, scale, lse, stream);
 }

@@ -1,5 +1,6 @@
-// fp32 kernels of the training step for gfx950 (the reference trains in fp32, vitm/training/train.py:208-241):
-// the pieces of the backward pass that are not GEMMs, the loss, gradient clipping and the optimizer update.
+// Kernels of the training step for gfx950 (vitm/training/train.py:208-241): the pieces of the backward pass that are not
+// GEMMs, the loss, gradient clipping and the optimizer update.  Activation-sized kernels exist for fp32 (the reference's
+// training precision) and bf16 (mixed precision: bf16 activations, fp32 statistics / reductions / parameters).
 //
 //   transpose          dst[n, m] = src[m, n], K padding of the destination zeroed (operands of the weight-gradient GEMM)
 //   colsum             out[c, d] = sum over the rows of chunk c of a[m, d] (* b[m, d]): bias / LayerScale / LayerNorm
@@ -16,21 +17,26 @@
 namespace {
 
 inline bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+__device__ __forceinline__ float ldv(const float* p) { return *p; }
+__device__ __forceinline__ float ldv(const bf16_t* p) { return bf2f(*p); }
+__device__ __forceinline__ void stv(float* p, float v) { *p = v; }
+__device__ __forceinline__ void stv(bf16_t* p, float v) { *p = f2bf(v); }
 inline unsigned stream_grid(int64_t items, int per = 256, int cap = 4096) {
   int64_t g = (items + per - 1) / per;
   return (unsigned)(g < 1 ? 1 : (g > cap ? cap : g));
 }
 
 // ---- transpose: 32x32 tiles through LDS ------------------------------------------------------------------
-__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ src, int64_t lds_, float* __restrict__ dst,
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_kernel(const T* __restrict__ src, int64_t lds_, T* __restrict__ dst,
                                                         int64_t ldd, int M, int N, int Mpad) {
-  __shared__ float tile[32][33];
+  __shared__ T tile[32][33];
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
   const int m0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int m = m0 + ty + 8 * i, n = n0 + tx;
-    tile[ty + 8 * i][tx] = (m < M && n < N) ? src[(int64_t)m * lds_ + n] : 0.f;
+    tile[ty + 8 * i][tx] = (m < M && n < N) ? src[(int64_t)m * lds_ + n] : (T)0;
   }
   __syncthreads();
 #pragma unroll
@@ -42,7 +48,8 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
 
 // ---- column sums ---------------------------------------------------------------------------------------------
 // workgroup = 64 columns x 4 row lanes; blockIdx.y = row chunk
-__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ a, int64_t lda, const float* __restrict__ b,
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ a, int64_t lda, const T* __restrict__ b,
                                                      int64_t ldb, float* __restrict__ out, int64_t ldo, int M, int D,
                                                      int rows_per_chunk) {
   __shared__ float sh[4][64];
@@ -54,8 +61,8 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ a
   float s = 0.f;
   if (col < D) {
     for (int m = r0 + rl; m < r1; m += 4) {
-      const float v = a[(int64_t)m * lda + col];
-      s += b ? v * b[(int64_t)m * ldb + col] : v;
+      const float v = ldv(a + (int64_t)m * lda + col);
+      s += b ? v * ldv(b + (int64_t)m * ldb + col) : v;
     }
   }
   sh[rl][threadIdx.x & 63] = s;
@@ -65,11 +72,12 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ a
 
 // ---- LayerNorm backward: one wave per row at a time, a workgroup of 4 waves strides over the rows ------------------
 constexpr int LN_MAXC = 4;   // 8-element chunks per lane: D <= 2048
-__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ x, int64_t ldx,
-                                                            const float* __restrict__ dy, int64_t lddy,
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict__ x, int64_t ldx,
+                                                            const T* __restrict__ dy, int64_t lddy,
                                                             const float* __restrict__ w, float eps,
-                                                            const float* __restrict__ dx_add, int64_t ldadd,
-                                                            float* __restrict__ dx, int64_t lddx,
+                                                            const T* __restrict__ dx_add, int64_t ldadd,
+                                                            T* __restrict__ dx, int64_t lddx,
                                                             float* __restrict__ dwp, float* __restrict__ dbp, int M, int D) {
   __shared__ float red[2][4][64 * 8];   // per wave, one 8-chunk at a time
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -93,8 +101,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
       const int c = (lane + 64 * t) * 8;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        xv[t][e] = c < D ? x[(int64_t)m * ldx + c + e] : 0.f;
-        gv[t][e] = c < D ? dy[(int64_t)m * lddy + c + e] : 0.f;
+        xv[t][e] = c < D ? ldv(x + (int64_t)m * ldx + c + e) : 0.f;
+        gv[t][e] = c < D ? ldv(dy + (int64_t)m * lddy + c + e) : 0.f;
         s += xv[t][e];
       }
     }
@@ -132,8 +140,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           float r = rstd * (gv[t][e] - c1 - xv[t][e] * c2);
-          if (dx_add) r += dx_add[(int64_t)m * ldadd + c + e];
-          dx[(int64_t)m * lddx + c + e] = r;
+          if (dx_add) r += ldv(dx_add + (int64_t)m * ldadd + c + e);
+          stv(dx + (int64_t)m * lddx + c + e, r);
         }
       }
     }
@@ -161,28 +169,30 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
 }
 
 // ---- GELU backward ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void gelu_bwd_kernel(const float* __restrict__ pre, int64_t ldp, const float* __restrict__ dh,
-                                                       int64_t ldh, float* __restrict__ dpre, int64_t ldd, int M, int D) {
+template <typename T>
+__global__ __launch_bounds__(256) void gelu_bwd_kernel(const T* __restrict__ pre, int64_t ldp, const T* __restrict__ dh,
+                                                       int64_t ldh, T* __restrict__ dpre, int64_t ldd, int M, int D) {
   const int64_t total = (int64_t)M * D;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t m = i / D;
     const int c = (int)(i - m * D);
-    const float v = pre[m * ldp + c];
+    const float v = ldv(pre + m * ldp + c);
     const float cdf = 0.5f * (1.0f + erf_as(v * 0.70710678118654752f));
     const float pdf = 0.3989422804014327f * __expf(-0.5f * v * v);
-    dpre[m * ldd + c] = dh[m * ldh + c] * fmaf(v, pdf, cdf);
+    stv(dpre + m * ldd + c, ldv(dh + m * ldh + c) * fmaf(v, pdf, cdf));
   }
 }
 
 // ---- LayerScale + residual add that keeps the branch output -------------------------------------------------------
-__global__ __launch_bounds__(256) void residual_scale_kernel(const float* __restrict__ r, int64_t ldr, const float* __restrict__ z,
-                                                             int64_t ldz, const float* __restrict__ g, float* __restrict__ out,
+template <typename T>
+__global__ __launch_bounds__(256) void residual_scale_kernel(const T* __restrict__ r, int64_t ldr, const T* __restrict__ z,
+                                                             int64_t ldz, const float* __restrict__ g, T* __restrict__ out,
                                                              int64_t ldo, int M, int D) {
   const int64_t total = (int64_t)M * D;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t m = i / D;
     const int c = (int)(i - m * D);
-    out[m * ldo + c] = fmaf(g[c], z[m * ldz + c], r[m * ldr + c]);
+    stv(out + m * ldo + c, fmaf(g[c], ldv(z + m * ldz + c), ldv(r + m * ldr + c)));
   }
 }
 
@@ -267,58 +277,71 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
 
 }  // namespace
 
-extern "C" int vitm_transpose_f32(const float* src, int64_t lds, float* dst, int64_t ldd, int M, int N, int m_pad,
-                                  vitm_stream_t stream) {
-  VITM_REQUIRE(src && dst, "vitm_transpose_f32: null pointer");
-  VITM_REQUIRE(M > 0 && N > 0 && lds >= N && m_pad >= M && ldd >= m_pad, "vitm_transpose_f32: bad shape");
+extern "C" int vitm_transpose(const void* src, int64_t lds, void* dst, int64_t ldd, int dtype, int M, int N, int m_pad,
+                              vitm_stream_t stream) {
+  VITM_REQUIRE(src && dst, "vitm_transpose: null pointer");
+  VITM_REQUIRE(dtype == VITM_BF16 || dtype == VITM_F32, "vitm_transpose: bad dtype %d", dtype);
+  VITM_REQUIRE(M > 0 && N > 0 && lds >= N && m_pad >= M && ldd >= m_pad, "vitm_transpose: bad shape");
   dim3 grid((unsigned)((m_pad + 31) / 32), (unsigned)((N + 31) / 32));
-  VITM_REQUIRE(grid.y < 65536, "vitm_transpose_f32: N too large");
-  hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, (hipStream_t)stream, src, lds, dst, ldd, M, N, m_pad);
-  VITM_CHECK_LAUNCH("vitm_transpose_f32");
+  VITM_REQUIRE(grid.y < 65536, "vitm_transpose: N too large");
+  if (dtype == VITM_F32) hipLaunchKernelGGL(transpose_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)src, lds, (float*)dst, ldd, M, N, m_pad);
+  else hipLaunchKernelGGL(transpose_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, lds, (bf16_t*)dst, ldd, M, N, m_pad);
+  VITM_CHECK_LAUNCH("vitm_transpose");
   return VITM_OK;
 }
 
-extern "C" int vitm_colsum_f32(const float* a, int64_t lda, const float* b, int64_t ldb, float* out, int64_t ldo,
-                               int M, int D, int nchunks, vitm_stream_t stream) {
-  VITM_REQUIRE(a && out, "vitm_colsum_f32: null pointer");
+extern "C" int vitm_colsum(const void* a, int64_t lda, const void* b, int64_t ldb, int dtype, float* out, int64_t ldo,
+                           int M, int D, int nchunks, vitm_stream_t stream) {
+  VITM_REQUIRE(a && out, "vitm_colsum: null pointer");
+  VITM_REQUIRE(dtype == VITM_BF16 || dtype == VITM_F32, "vitm_colsum: bad dtype %d", dtype);
   VITM_REQUIRE(M > 0 && D > 0 && nchunks > 0 && nchunks < 65536 && lda >= D && ldo >= D && (!b || ldb >= D),
-               "vitm_colsum_f32: bad shape");
+               "vitm_colsum: bad shape");
   const int rpc = (M + nchunks - 1) / nchunks;
-  hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((D + 63) / 64), (unsigned)nchunks), dim3(256), 0, (hipStream_t)stream, a, lda,
-                     b, ldb, out, ldo, M, D, rpc);
-  VITM_CHECK_LAUNCH("vitm_colsum_f32");
+  const dim3 grid((unsigned)((D + 63) / 64), (unsigned)nchunks);
+  if (dtype == VITM_F32) hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)a, lda, (const float*)b, ldb, out, ldo, M, D, rpc);
+  else hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)a, lda, (const bf16_t*)b, ldb, out, ldo, M, D, rpc);
+  VITM_CHECK_LAUNCH("vitm_colsum");
   return VITM_OK;
 }
 
-extern "C" int vitm_layernorm_bwd_f32(const float* x, int64_t ldx, const float* dy, int64_t lddy, const float* w, float eps,
-                                      const float* dx_add, int64_t ldadd, float* dx, int64_t lddx, float* dw_partial,
-                                      float* db_partial, int nblocks, int M, int D, vitm_stream_t stream) {
-  VITM_REQUIRE(x && dy && w && dx && dw_partial && db_partial, "vitm_layernorm_bwd_f32: null pointer");
-  VITM_REQUIRE(M > 0 && D > 0 && D % 8 == 0 && D <= 64 * 8 * LN_MAXC, "vitm_layernorm_bwd_f32: D=%d must be a multiple of 8 and <= %d", D, 64 * 8 * LN_MAXC);
-  VITM_REQUIRE(ldx >= D && lddy >= D && lddx >= D && (!dx_add || ldadd >= D) && nblocks > 0, "vitm_layernorm_bwd_f32: bad leading dimension");
-  hipLaunchKernelGGL(layernorm_bwd_kernel, dim3((unsigned)nblocks), dim3(256), 0, (hipStream_t)stream, x, ldx, dy, lddy, w, eps,
-                     dx_add, ldadd, dx, lddx, dw_partial, db_partial, M, D);
-  VITM_CHECK_LAUNCH("vitm_layernorm_bwd_f32");
+extern "C" int vitm_layernorm_bwd(const void* x, int64_t ldx, const void* dy, int64_t lddy, const float* w, float eps,
+                                  const void* dx_add, int64_t ldadd, void* dx, int64_t lddx, int dtype, float* dw_partial,
+                                  float* db_partial, int nblocks, int M, int D, vitm_stream_t stream) {
+  VITM_REQUIRE(x && dy && w && dx && dw_partial && db_partial, "vitm_layernorm_bwd: null pointer");
+  VITM_REQUIRE(dtype == VITM_BF16 || dtype == VITM_F32, "vitm_layernorm_bwd: bad dtype %d", dtype);
+  VITM_REQUIRE(M > 0 && D > 0 && D % 8 == 0 && D <= 64 * 8 * LN_MAXC, "vitm_layernorm_bwd: D=%d must be a multiple of 8 and <= %d", D, 64 * 8 * LN_MAXC);
+  VITM_REQUIRE(ldx >= D && lddy >= D && lddx >= D && (!dx_add || ldadd >= D) && nblocks > 0, "vitm_layernorm_bwd: bad leading dimension");
+  if (dtype == VITM_F32)
+    hipLaunchKernelGGL(layernorm_bwd_kernel<float>, dim3((unsigned)nblocks), dim3(256), 0, (hipStream_t)stream, (const float*)x, ldx, (const float*)dy, lddy, w, eps,
+                       (const float*)dx_add, ldadd, (float*)dx, lddx, dw_partial, db_partial, M, D);
+  else
+    hipLaunchKernelGGL(layernorm_bwd_kernel<bf16_t>, dim3((unsigned)nblocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, (const bf16_t*)dy, lddy, w, eps,
+                       (const bf16_t*)dx_add, ldadd, (bf16_t*)dx, lddx, dw_partial, db_partial, M, D);
+  VITM_CHECK_LAUNCH("vitm_layernorm_bwd");
   return VITM_OK;
 }
 
-extern "C" int vitm_gelu_bwd_f32(const float* pre, int64_t ldp, const float* dh, int64_t ldh, float* dpre, int64_t ldd, int M,
-                                 int D, vitm_stream_t stream) {
-  VITM_REQUIRE(pre && dh && dpre, "vitm_gelu_bwd_f32: null pointer");
-  VITM_REQUIRE(M > 0 && D > 0 && ldp >= D && ldh >= D && ldd >= D, "vitm_gelu_bwd_f32: bad shape");
-  hipLaunchKernelGGL(gelu_bwd_kernel, dim3(stream_grid((int64_t)M * D)), dim3(256), 0, (hipStream_t)stream, pre, ldp, dh, ldh, dpre,
-                     ldd, M, D);
-  VITM_CHECK_LAUNCH("vitm_gelu_bwd_f32");
+extern "C" int vitm_gelu_bwd(const void* pre, int64_t ldp, const void* dh, int64_t ldh, void* dpre, int64_t ldd, int dtype, int M,
+                             int D, vitm_stream_t stream) {
+  VITM_REQUIRE(pre && dh && dpre, "vitm_gelu_bwd: null pointer");
+  VITM_REQUIRE(dtype == VITM_BF16 || dtype == VITM_F32, "vitm_gelu_bwd: bad dtype %d", dtype);
+  VITM_REQUIRE(M > 0 && D > 0 && ldp >= D && ldh >= D && ldd >= D, "vitm_gelu_bwd: bad shape");
+  const dim3 grid(stream_grid((int64_t)M * D));
+  if (dtype == VITM_F32) hipLaunchKernelGGL(gelu_bwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)pre, ldp, (const float*)dh, ldh, (float*)dpre, ldd, M, D);
+  else hipLaunchKernelGGL(gelu_bwd_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)pre, ldp, (const bf16_t*)dh, ldh, (bf16_t*)dpre, ldd, M, D);
+  VITM_CHECK_LAUNCH("vitm_gelu_bwd");
   return VITM_OK;
 }
 
-extern "C" int vitm_residual_scale_f32(const float* resid, int64_t ldr, const float* z, int64_t ldz, const float* gamma, float* out,
-                                       int64_t ldo, int M, int D, vitm_stream_t stream) {
-  VITM_REQUIRE(resid && z && gamma && out, "vitm_residual_scale_f32: null pointer");
-  VITM_REQUIRE(M > 0 && D > 0 && ldr >= D && ldz >= D && ldo >= D, "vitm_residual_scale_f32: bad shape");
-  hipLaunchKernelGGL(residual_scale_kernel, dim3(stream_grid((int64_t)M * D)), dim3(256), 0, (hipStream_t)stream, resid, ldr, z, ldz,
-                     gamma, out, ldo, M, D);
-  VITM_CHECK_LAUNCH("vitm_residual_scale_f32");
+extern "C" int vitm_residual_scale(const void* resid, int64_t ldr, const void* z, int64_t ldz, const float* gamma, void* out,
+                                   int64_t ldo, int dtype, int M, int D, vitm_stream_t stream) {
+  VITM_REQUIRE(resid && z && gamma && out, "vitm_residual_scale: null pointer");
+  VITM_REQUIRE(dtype == VITM_BF16 || dtype == VITM_F32, "vitm_residual_scale: bad dtype %d", dtype);
+  VITM_REQUIRE(M > 0 && D > 0 && ldr >= D && ldz >= D && ldo >= D, "vitm_residual_scale: bad shape");
+  const dim3 grid(stream_grid((int64_t)M * D));
+  if (dtype == VITM_F32) hipLaunchKernelGGL(residual_scale_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)resid, ldr, (const float*)z, ldz, gamma, (float*)out, ldo, M, D);
+  else hipLaunchKernelGGL(residual_scale_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)resid, ldr, (const bf16_t*)z, ldz, gamma, (bf16_t*)out, ldo, M, D);
+  VITM_CHECK_LAUNCH("vitm_residual_scale");
   return VITM_OK;
 }
 

@@ -55,18 +55,20 @@ SIGNATURES = {
     "vitm_gemm_uses_big_tile": (c_int, [c_int, c_int, c_int]),
     "vitm_im2col": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int64, c_int, c_int,
                             c_void_p]),
-    "vitm_residual_scale_f32": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int, c_int,
-                                        c_void_p]),
+    "vitm_residual_scale": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int, c_int, c_int,
+                                    c_void_p]),
     "vitm_gelu": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
     "vitm_attention_f32_lse": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int, c_int, c_int, c_int, c_float,
                                        c_void_p]),
     "vitm_attention_bwd_f32": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64,
                                        c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p]),
-    "vitm_transpose_f32": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
-    "vitm_colsum_f32": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
-    "vitm_layernorm_bwd_f32": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_float, c_void_p, c_int64, c_void_p,
-                                       c_int64, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
-    "vitm_gelu_bwd_f32": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_void_p]),
+    "vitm_attention_lse": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int, c_int, c_int, c_int, c_float,
+                                   c_void_p]),
+    "vitm_transpose": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p]),
+    "vitm_colsum": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
+    "vitm_layernorm_bwd": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_float, c_void_p, c_int64, c_void_p,
+                                   c_int64, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "vitm_gelu_bwd": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
     "vitm_cross_entropy_f32": (c_int, [c_void_p, c_int64, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int64, c_void_p]),
     "vitm_grad_clip_f32": (c_int, [c_void_p, c_int64, c_float, c_void_p, c_void_p, c_void_p]),
     "vitm_grad_clip_scratch_floats": (c_int, []),

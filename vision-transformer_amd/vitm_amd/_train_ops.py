@@ -1,4 +1,7 @@
-"""Torch-tensor front end of the fp32 training entry points of the C ABI (backward pieces, loss, clip, AdamW)."""
+"""Torch-tensor front end of the training entry points of the C ABI (backward pieces, loss, clip, AdamW).
+
+Activation-sized tensors are fp32 or bf16 (one dtype per call); statistics, reductions, parameter gradients, the loss
+and the optimizer state are always fp32."""
 from __future__ import annotations
 
 from typing import Optional
@@ -6,10 +9,11 @@ from typing import Optional
 import torch
 
 from . import _lib
-from ._ops import _p, _stream, round_up, k_multiple, pack_linear, gemm, EPI_BIAS
+from ._ops import _p, _dt, _stream, round_up, k_multiple, pack_linear, gemm, to_f32, to_bf16, EPI_BIAS
 
 COLSUM_CHUNKS = 64
 LN_BWD_BLOCKS = 256
+F32 = torch.float32
 
 
 def _f32(t: torch.Tensor) -> torch.Tensor:
@@ -17,53 +21,82 @@ def _f32(t: torch.Tensor) -> torch.Tensor:
     return t
 
 
+def _rm(*ts: torch.Tensor) -> int:
+    """dtype code shared by row-major operands of one call."""
+    d = ts[0].dtype
+    for t in ts:
+        assert t.dtype == d and t.stride(-1) == 1, "row-major tensors of one dtype expected"
+    return _dt(ts[0])
+
+
 def attention_lse(qkv, out, lse, B, N, H, hd, scale) -> None:
-    _lib.check(_lib.load().vitm_attention_f32_lse(_p(_f32(qkv)), qkv.stride(0), _p(_f32(out)), out.stride(0), _p(lse), B, N, H,
-                                                  hd, float(scale), _stream()), "vitm_attention_f32_lse")
+    lib = _lib.load()
+    if qkv.dtype == torch.bfloat16:
+        assert out.dtype == torch.bfloat16
+        _lib.check(lib.vitm_attention_lse(_p(qkv), qkv.stride(0), _p(out), out.stride(0), _p(_f32(lse)), B, N, H, hd,
+                                          float(scale), _stream()), "vitm_attention_lse")
+        return
+    _lib.check(lib.vitm_attention_f32_lse(_p(_f32(qkv)), qkv.stride(0), _p(_f32(out)), out.stride(0), _p(lse), B, N, H,
+                                          hd, float(scale), _stream()), "vitm_attention_f32_lse")
 
 
 def attention_bwd(qkv, o, d_o, lse, dqkv, B, N, H, hd, scale) -> None:
-    delta = torch.empty(B * H * N, dtype=torch.float32, device=qkv.device)
-    _lib.check(_lib.load().vitm_attention_bwd_f32(_p(_f32(qkv)), qkv.stride(0), _p(_f32(o)), o.stride(0), _p(_f32(d_o)),
-                                                  d_o.stride(0), _p(lse), _p(_f32(dqkv)), dqkv.stride(0), _p(delta), B, N, H,
-                                                  hd, float(scale), _stream()), "vitm_attention_bwd_f32")
+    lib = _lib.load()
+    if qkv.dtype == torch.bfloat16:
+        # bf16 activations: the backward runs on fp32 copies (fp32 products and sums), dqkv is rounded once at the end
+        q32, o32, do32 = to_f32(qkv), to_f32(o), to_f32(d_o)
+        dq32 = torch.empty(qkv.shape, dtype=F32, device=qkv.device)
+        _lib.check(lib.vitm_attention_bwd_f32(_p(q32), q32.stride(0), _p(o32), o32.stride(0), _p(do32), do32.stride(0),
+                                              _p(_f32(lse)), _p(dq32), dq32.stride(0), _p(_delta(qkv, B, H, N)), B, N, H,
+                                              hd, float(scale), _stream()), "vitm_attention_bwd_f32")
+        assert dqkv.is_contiguous()
+        _lib.check(lib.vitm_cast_f32_to_bf16(_p(dq32), _p(dqkv), dq32.numel(), _stream()), "vitm_cast_f32_to_bf16")
+        return
+    _lib.check(lib.vitm_attention_bwd_f32(_p(_f32(qkv)), qkv.stride(0), _p(_f32(o)), o.stride(0), _p(_f32(d_o)),
+                                          d_o.stride(0), _p(lse), _p(_f32(dqkv)), dqkv.stride(0), _p(_delta(qkv, B, H, N)),
+                                          B, N, H, hd, float(scale), _stream()), "vitm_attention_bwd_f32")
+
+
+def _delta(ref, B, H, N):
+    return torch.empty(B * H * N, dtype=F32, device=ref.device)
 
 
 def transpose(src: torch.Tensor, M: int, N: int, m_pad: Optional[int] = None) -> torch.Tensor:
-    """[M, N] (row stride src.stride(0)) -> new [N, m_pad] with the pad columns zero."""
+    """[M, N] (row stride src.stride(0)) -> new [N, m_pad] of the same dtype with the pad columns zero."""
     m_pad = M if m_pad is None else m_pad
-    dst = torch.empty((N, m_pad), dtype=torch.float32, device=src.device)
-    _lib.check(_lib.load().vitm_transpose_f32(_p(_f32(src)), src.stride(0), _p(dst), m_pad, M, N, m_pad, _stream()),
-               "vitm_transpose_f32")
+    dst = torch.empty((N, m_pad), dtype=src.dtype, device=src.device)
+    _lib.check(_lib.load().vitm_transpose(_p(src), src.stride(0), _p(dst), m_pad, _rm(src), M, N, m_pad, _stream()),
+               "vitm_transpose")
     return dst
 
 
 def colsum(a: torch.Tensor, M: int, D: int, b: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """out[d] = sum_m a[m, d] * (b[m, d] if b is given else 1), deterministic two-stage reduction."""
+    """out[d] = sum_m a[m, d] * (b[m, d] if b is given else 1) in fp32, deterministic two-stage reduction."""
     lib = _lib.load()
     if out is None:
-        out = torch.empty(D, dtype=torch.float32, device=a.device)
+        out = torch.empty(D, dtype=F32, device=a.device)
+    dt = _rm(a) if b is None else _rm(a, b)
     nch = min(COLSUM_CHUNKS, M)
+    ldb = 0 if b is None else b.stride(0)
     if nch > 1:
-        part = torch.empty((nch, D), dtype=torch.float32, device=a.device)
-        _lib.check(lib.vitm_colsum_f32(_p(_f32(a)), a.stride(0), _p(b), 0 if b is None else b.stride(0), _p(part), D, M, D, nch,
-                                       _stream()), "vitm_colsum_f32")
-        _lib.check(lib.vitm_colsum_f32(_p(part), D, None, 0, _p(out), D, nch, D, 1, _stream()), "vitm_colsum_f32")
+        part = torch.empty((nch, D), dtype=F32, device=a.device)
+        _lib.check(lib.vitm_colsum(_p(a), a.stride(0), _p(b), ldb, dt, _p(part), D, M, D, nch, _stream()), "vitm_colsum")
+        _lib.check(lib.vitm_colsum(_p(part), D, None, 0, _lib.F32, _p(out), D, nch, D, 1, _stream()), "vitm_colsum")
     else:
-        _lib.check(lib.vitm_colsum_f32(_p(_f32(a)), a.stride(0), _p(b), 0 if b is None else b.stride(0), _p(out), D, M, D, 1,
-                                       _stream()), "vitm_colsum_f32")
+        _lib.check(lib.vitm_colsum(_p(a), a.stride(0), _p(b), ldb, dt, _p(out), D, M, D, 1, _stream()), "vitm_colsum")
     return out
 
 
 def layernorm_bwd(x, dy, w, eps, M, D, dx, dx_add=None, dw_out=None, db_out=None):
     """dx (= dx_add + LayerNorm backward) and, when dw_out / db_out are given, the parameter gradients."""
     nb = min(LN_BWD_BLOCKS, (M + 3) // 4)
-    dwp = torch.empty((nb, D), dtype=torch.float32, device=x.device)
-    dbp = torch.empty((nb, D), dtype=torch.float32, device=x.device)
-    _lib.check(_lib.load().vitm_layernorm_bwd_f32(
-        _p(_f32(x)), x.stride(0), _p(_f32(dy)), dy.stride(0), _p(w), float(eps), _p(dx_add),
-        0 if dx_add is None else dx_add.stride(0), _p(_f32(dx)), dx.stride(0), _p(dwp), _p(dbp), nb, M, D, _stream()),
-        "vitm_layernorm_bwd_f32")
+    dwp = torch.empty((nb, D), dtype=F32, device=x.device)
+    dbp = torch.empty((nb, D), dtype=F32, device=x.device)
+    dt = _rm(x, dy, dx) if dx_add is None else _rm(x, dy, dx, dx_add)
+    _lib.check(_lib.load().vitm_layernorm_bwd(
+        _p(x), x.stride(0), _p(dy), dy.stride(0), _p(_f32(w)), float(eps), _p(dx_add),
+        0 if dx_add is None else dx_add.stride(0), _p(dx), dx.stride(0), dt, _p(dwp), _p(dbp), nb, M, D, _stream()),
+        "vitm_layernorm_bwd")
     if dw_out is not None:
         colsum(dwp, nb, D, out=dw_out)
     if db_out is not None:
@@ -71,13 +104,13 @@ def layernorm_bwd(x, dy, w, eps, M, D, dx, dx_add=None, dw_out=None, db_out=None
 
 
 def gelu_bwd(pre, dh, dpre, M, D) -> None:
-    _lib.check(_lib.load().vitm_gelu_bwd_f32(_p(_f32(pre)), pre.stride(0), _p(_f32(dh)), dh.stride(0), _p(_f32(dpre)),
-                                             dpre.stride(0), M, D, _stream()), "vitm_gelu_bwd_f32")
+    _lib.check(_lib.load().vitm_gelu_bwd(_p(pre), pre.stride(0), _p(dh), dh.stride(0), _p(dpre), dpre.stride(0),
+                                         _rm(pre, dh, dpre), M, D, _stream()), "vitm_gelu_bwd")
 
 
 def residual_scale(resid, z, gamma, out, M, D) -> None:
-    _lib.check(_lib.load().vitm_residual_scale_f32(_p(_f32(resid)), resid.stride(0), _p(_f32(z)), z.stride(0), _p(gamma),
-                                                   _p(_f32(out)), out.stride(0), M, D, _stream()), "vitm_residual_scale_f32")
+    _lib.check(_lib.load().vitm_residual_scale(_p(resid), resid.stride(0), _p(z), z.stride(0), _p(_f32(gamma)), _p(out),
+                                               out.stride(0), _rm(resid, z, out), M, D, _stream()), "vitm_residual_scale")
 
 
 def cross_entropy(logits, labels, want_grad=True):
@@ -108,26 +141,28 @@ def adamw(p, g, m, v, lr, beta1, beta2, eps, wd, step) -> None:
 
 # ---- Linear backward out of the forward GEMM ----------------------------------------------------------------------
 def linear_dx(dy: torch.Tensor, weight: torch.Tensor, M: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """dx[M, K] = dy[M, N] . W[N, K]  (nn.Linear weight layout): the forward GEMM with W^T as the packed operand."""
+    """dx[M, K] = dy[M, N] . W[N, K]  (nn.Linear weight layout): the forward GEMM with W^T as the packed operand.
+    dy's dtype is the compute dtype (the fp32 master weight is packed to it); dx comes back in it."""
     N, K = weight.shape
-    wt = transpose(weight.detach().contiguous(), N, K)              # [K, N]
-    pk = pack_linear(wt, None, dtype=torch.float32)                 # rows K (padded to 8), cols N (padded to 64)
+    wt = transpose(weight.detach().contiguous(), N, K)              # [K, N], the weight's own dtype
+    pk = pack_linear(wt, None, dtype=dy.dtype)                      # rows K (padded to 8), cols N (padded to 64)
     dyp = dy
     if dy.shape[1] < pk.kpad:                                       # pad dy's columns to the GEMM's K multiple
-        dyp = torch.zeros((M, pk.kpad), dtype=torch.float32, device=dy.device)
+        dyp = torch.zeros((M, pk.kpad), dtype=dy.dtype, device=dy.device)
         dyp[:, :dy.shape[1]] = dy
     if out is None:
-        out = torch.empty((M, pk.npad), dtype=torch.float32, device=dy.device)
+        out = torch.empty((M, pk.npad), dtype=dy.dtype, device=dy.device)
     gemm(dyp, pk, out, EPI_BIAS, M)
     return out
 
 
 def linear_dw(dy: torch.Tensor, x: torch.Tensor, M: int, N: int, K: int) -> torch.Tensor:
-    """dW[N, K] = dy[:, :N]^T . x[:, :K]: the forward GEMM on the two transposed activations (rows padded to its K multiple)."""
+    """dW[N, K] (fp32) = dy[:, :N]^T . x[:, :K]: the forward GEMM on the two transposed activations (rows padded to
+    its K multiple); bf16 operands accumulate and store in fp32."""
     mp = round_up(M, k_multiple())
     dyt = transpose(dy, M, N, mp)                                   # [N, mp]
     xt = transpose(x, M, K, mp)                                     # [K, mp]
-    pk = pack_linear(xt, None, dtype=torch.float32)                 # "weight" = x^T: rows K, cols mp
-    out = torch.empty((N, pk.npad), dtype=torch.float32, device=dy.device)
+    pk = pack_linear(xt, None, dtype=dy.dtype)                      # "weight" = x^T: rows K, cols mp
+    out = torch.empty((N, pk.npad), dtype=F32, device=dy.device)
     gemm(dyt, pk, out, EPI_BIAS, N)
     return out[:, :K]

@@ -2,7 +2,7 @@
 
 API mirror of the reference's ``VITC`` (vitm/models/classifier.py:6-39): ``VITC(vit_model)`` with
 attributes ``vit_model`` and ``head = nn.Linear(embed_dim, num_classes)`` and state_dict keys
-``vit_model.*``, ``head.{weight,bias}``.  With autograd enabled, fp32 images and fp32 parameters that require
+``vit_model.*``, ``head.{weight,bias}``.  With autograd enabled, fp32 or bf16 images and fp32 parameters that require
 gradients, ``forward`` returns logits carrying a graph (``vitm_amd.training``); otherwise it is inference.  When the backbone is this package's ``VisionTransformer`` the final
 LayerNorm is applied to the class-token rows only (folded into the head GEMM on the bf16 path).
 """
@@ -25,8 +25,10 @@ class VITC(nn.Module):
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         """(B, C, H, W) images -> (B, num_classes) logits, in the dtype of ``x``."""
         _ops.require_cuda(x, "VITC.forward")
-        if torch.is_grad_enabled() and x.dtype == torch.float32 and any(p.requires_grad for p in self.parameters()):
-            # training: the fp32 forward that keeps its activations, with a hand-written backward behind it
+        if (torch.is_grad_enabled() and x.dtype in (torch.float32, torch.bfloat16)
+                and any(p.requires_grad for p in self.parameters())):
+            # training: the forward that keeps its activations, with a hand-written backward behind it (fp32 images:
+            # fp32 arithmetic; bf16 images: bf16 activations and matrix cores over the fp32 master parameters)
             from .. import training
             if training.supported(self) is None and all(p.dtype == torch.float32 for p in self.parameters()):
                 return training.vitc_forward_with_grad(self, x)

@@ -1,4 +1,4 @@
-"""The training step of ``VITC`` on MI355X, fp32.
+"""The training step of ``VITC`` on MI355X: fp32 (the reference's precision) or bf16 mixed precision.
 
 Counterpart of the loop body of the reference's vitm/training/train.py:215-224::
 
@@ -8,9 +8,12 @@ Counterpart of the loop body of the reference's vitm/training/train.py:215-224::
 with every tensor operation in hand-written HIP kernels: the forward keeps the activations the backward needs, the
 backward is written out by hand (GEMMs of the forward kernel family on transposed operands, fp32 attention backward,
 LayerNorm / GELU backward, deterministic column-sum reductions), the loss, the gradient clip and the AdamW update are
-kernels too.  The reference trains in fp32 (no autocast), so does this path.  PyTorch supplies memory, the autograd
-hook-up (one ``autograd.Function`` for the whole model, one for the loss) and, for data parallelism, the RCCL
-all-reduce of the flat gradient buffer.
+kernels too.  The reference trains in fp32 (no autocast), and fp32 images take that path.  bf16 images (or
+``compute_dtype=torch.bfloat16``) take the mixed-precision path: parameters, their gradients, the optimizer state,
+LayerNorm / softmax statistics, every reduction and the loss stay fp32; activations, their gradients and the GEMM
+operands are bf16 on the bf16 matrix cores with fp32 accumulation (weight gradients are stored in fp32 straight from
+the accumulators).  PyTorch supplies memory, the autograd hook-up (one ``autograd.Function`` for the whole model, one
+for the loss) and, for data parallelism, the RCCL all-reduce of the flat gradient buffer.
 
 Supported: ``VITC(VisionTransformer)`` built from this package's sequential ``Block`` with LayerNorm (or Identity)
 norms, learnable position embedding, GELU MLP, no qk-norm -- the configuration the reference's training script builds
@@ -38,15 +41,15 @@ def _ld(D: int) -> int:
     return _ops.round_up(D, _ops.k_multiple())
 
 
-def _buf(M: int, width: int, device, like_width: Optional[int] = None) -> torch.Tensor:
-    """[M, roundup(width, 64)] fp32; zero-filled when it has pad columns (they feed GEMMs as K padding)."""
+def _buf(M: int, width: int, device, dt: torch.dtype = F32) -> torch.Tensor:
+    """[M, roundup(width, 64)] in the compute dtype; zero-filled when it has pad columns (they feed GEMMs as K padding)."""
     w = _ld(width)
-    return torch.zeros((M, w), dtype=F32, device=device) if w != width else torch.empty((M, w), dtype=F32, device=device)
+    return torch.zeros((M, w), dtype=dt, device=device) if w != width else torch.empty((M, w), dtype=dt, device=device)
 
 
-def _pk(w: torch.Tensor, b: Optional[torch.Tensor]):
-    """fp32 packed weight for this step (weights change every step: no caching)."""
-    return _ops.pack_linear(w, b, dtype=F32)
+def _pk(w: torch.Tensor, b: Optional[torch.Tensor], dt: torch.dtype = F32):
+    """The fp32 master weight packed in the compute dtype for this step (weights change every step: no caching)."""
+    return _ops.pack_linear(w, b, dtype=dt)
 
 
 def _ln(mod: nn.Module, what: str):
@@ -77,7 +80,7 @@ def supported(model) -> Optional[str]:
 # forward that keeps what the backward needs
 # ----------------------------------------------------------------------------------------------------------------
 def _block_forward(blk: Block, x: torch.Tensor, B: int, N: int) -> (torch.Tensor, dict):
-    D, M, dev = blk.dim, B * N, x.device
+    D, M, dev, cd = blk.dim, B * N, x.device, x.dtype
     attn, mlp = blk.attn, blk.mlp
     attn._check()
     _check_gelu(mlp.ac1, "MLP")
@@ -86,36 +89,37 @@ def _block_forward(blk: Block, x: torch.Tensor, B: int, N: int) -> (torch.Tensor
     s = {"x": x}
     n1 = x
     if ln1 is not None:
-        n1 = _buf(M, D, dev)
+        n1 = _buf(M, D, dev, cd)
         _ops.layernorm(x, n1, M, D, ln1[0], ln1[1], ln1[2])
-    qkv = torch.empty((M, 3 * D), dtype=F32, device=dev)
-    _ops.gemm(n1, _pk(attn.qkv.weight, attn.qkv.bias), qkv, _ops.EPI_BIAS, M)
-    o = _buf(M, D, dev)
+    qkv = torch.empty((M, 3 * D), dtype=cd, device=dev)
+    _ops.gemm(n1, _pk(attn.qkv.weight, attn.qkv.bias, cd), qkv, _ops.EPI_BIAS, M)
+    o = _buf(M, D, dev, cd)
     lse = torch.empty(B * H * N, dtype=F32, device=dev)
     T.attention_lse(qkv, o, lse, B, N, H, hd, attn.scale)
-    z1 = torch.empty((M, _ops.round_up(D, 8)), dtype=F32, device=dev)
-    _ops.gemm(o, _pk(attn.proj.weight, attn.proj.bias), z1, _ops.EPI_BIAS, M)
-    x1 = _buf(M, D, dev)
+    z1 = torch.empty((M, _ops.round_up(D, 8)), dtype=cd, device=dev)
+    _ops.gemm(o, _pk(attn.proj.weight, attn.proj.bias, cd), z1, _ops.EPI_BIAS, M)
+    x1 = _buf(M, D, dev, cd)
     T.residual_scale(x, z1, _ops.f32vec(blk.ls1.gamma), x1, M, D)
     n2 = x1
     if ln2 is not None:
-        n2 = n1 if ln1 is not None else _buf(M, D, dev)       # reuse the scratch
+        n2 = n1 if ln1 is not None else _buf(M, D, dev, cd)       # reuse the scratch
         _ops.layernorm(x1, n2, M, D, ln2[0], ln2[1], ln2[2])
-    pre = _buf(M, hid, dev)
-    p1 = _pk(mlp.linear_layer1.weight, mlp.linear_layer1.bias)
+    pre = _buf(M, hid, dev, cd)
+    p1 = _pk(mlp.linear_layer1.weight, mlp.linear_layer1.bias, cd)
     _ops.gemm(n2, p1, pre, _ops.EPI_BIAS, M)
-    h = _buf(M, hid, dev)
+    h = _buf(M, hid, dev, cd)
     _ops.gelu(pre, h, M, _ops.round_up(hid, 8))
-    z2 = torch.empty((M, _ops.round_up(D, 8)), dtype=F32, device=dev)
-    _ops.gemm(h, _pk(mlp.linear_layer2.weight, mlp.linear_layer2.bias), z2, _ops.EPI_BIAS, M)
-    x2 = _buf(M, D, dev)
+    z2 = torch.empty((M, _ops.round_up(D, 8)), dtype=cd, device=dev)
+    _ops.gemm(h, _pk(mlp.linear_layer2.weight, mlp.linear_layer2.bias, cd), z2, _ops.EPI_BIAS, M)
+    x2 = _buf(M, D, dev, cd)
     T.residual_scale(x1, z2, _ops.f32vec(blk.ls2.gamma), x2, M, D)
     s.update(qkv=qkv, o=o, lse=lse, z1=z1, x1=x1, pre=pre, z2=z2)
     return x2, s
 
 
-def forward_train(model, img: torch.Tensor):
-    """(logits [B, C], saved state) -- the fp32 forward of VITC with the activations of the backward kept."""
+def forward_train(model, img: torch.Tensor, compute_dtype: Optional[torch.dtype] = None):
+    """(fp32 logits [B, C], saved state) -- the forward of VITC with the activations of the backward kept, in
+    ``compute_dtype`` (default: the images' dtype)."""
     vt: VisionTransformer = model.vit_model
     pe: PatchEmbed = vt.patch_embed
     dev = img.device
@@ -129,12 +133,13 @@ def forward_train(model, img: torch.Tensor):
     if D % 8 != 0:
         raise NotImplementedError("the training path needs embed_dim % 8 == 0")
     f = _ops.f32vec
-    S = {"B": B, "N": N, "M": M, "D": D, "has_cls": has_cls}
+    cd = _ops.compute_dtype(img) if compute_dtype is None else compute_dtype
+    S = {"B": B, "N": N, "M": M, "D": D, "has_cls": has_cls, "cd": cd}
 
-    pk_pe = _pk(pe.projection.weight, pe.projection.bias)
-    A = torch.empty((M, pk_pe.kpad), dtype=F32, device=dev)
+    pk_pe = _pk(pe.projection.weight, pe.projection.bias, cd)
+    A = torch.empty((M, pk_pe.kpad), dtype=cd, device=dev)
     _ops.im2col(img.contiguous(), A, pe.patch_size, pk_pe.kpad, has_cls)       # class-token rows are zero rows
-    x = _buf(M, D, dev)
+    x = _buf(M, D, dev, cd)
     _ops.gemm(A, pk_pe, x, _ops.EPI_BIAS, M)
     S["A"] = A
     en = _ln(pe.norm_layer, "PatchEmbed.norm_layer")
@@ -157,10 +162,10 @@ def forward_train(model, img: torch.Tensor):
     fin = _ln(vt.norm_final, "VisionTransformer.norm_final")
     nf = xc
     if fin is not None:
-        nf = _buf(B, D, dev)
+        nf = _buf(B, D, dev, cd)
         _ops.layernorm(xc, nf, B, D, fin[0], fin[1], fin[2])
     S["nf"] = nf
-    pk_h = _pk(model.head.weight, model.head.bias)
+    pk_h = _pk(model.head.weight, model.head.bias, cd)
     logits = torch.empty((B, pk_h.npad), dtype=F32, device=dev)
     _ops.gemm(nf, pk_h, logits, _ops.EPI_BIAS, B)
     return logits[:, :model.head.out_features], S
@@ -179,7 +184,7 @@ def _linear_backward(G: Dict, lin: nn.Linear, dy: torch.Tensor, x_in: torch.Tens
 
 
 def _block_backward(G: Dict, blk: Block, s: dict, dx2: torch.Tensor, B: int, N: int) -> torch.Tensor:
-    D, M, dev = blk.dim, B * N, dx2.device
+    D, M, dev, cd = blk.dim, B * N, dx2.device, dx2.dtype
     attn, mlp = blk.attn, blk.mlp
     H, hd, hid = attn.num_heads, attn.head_dim, mlp.hidden_features
     ln1, ln2 = _ln(blk.norm1, "Block.norm1"), _ln(blk.norm2, "Block.norm2")
@@ -187,19 +192,19 @@ def _block_backward(G: Dict, blk: Block, s: dict, dx2: torch.Tensor, B: int, N: 
 
     # ---- MLP branch: x2 = x1 + g2 * z2, z2 = fc2(gelu(pre)), pre = fc1(LN2(x1))
     G[blk.ls2.gamma] = T.colsum(dx2, M, D, s["z2"])
-    dz2 = torch.empty((M, _ops.round_up(D, 8)), dtype=F32, device=dev)
+    dz2 = torch.empty((M, _ops.round_up(D, 8)), dtype=cd, device=dev)
     _ops.scale_channels(dx2[:, :dz2.shape[1]] if dx2.shape[1] != dz2.shape[1] else dx2, dz2, M, _ops.round_up(D, 8), _pad8(g2))
-    h = _buf(M, hid, dev)
+    h = _buf(M, hid, dev, cd)
     _ops.gelu(s["pre"], h, M, _ops.round_up(hid, 8))
     dh = _linear_backward(G, mlp.linear_layer2, dz2, h, M)
     dpre = h                                              # reuse: h is dead after the weight gradient
     T.gelu_bwd(s["pre"], dh, dpre, M, hid)
     n2 = s["x1"]
     if ln2 is not None:
-        n2 = _buf(M, D, dev)
+        n2 = _buf(M, D, dev, cd)
         _ops.layernorm(s["x1"], n2, M, D, ln2[0], ln2[1], ln2[2])
     dn2 = _linear_backward(G, mlp.linear_layer1, dpre, n2, M)
-    dx1 = _buf(M, D, dev)
+    dx1 = _buf(M, D, dev, cd)
     if ln2 is not None:
         G[ln2[3]] = torch.empty(D, dtype=F32, device=dev)
         G[ln2[4]] = torch.empty(D, dtype=F32, device=dev)
@@ -212,14 +217,14 @@ def _block_backward(G: Dict, blk: Block, s: dict, dx2: torch.Tensor, B: int, N: 
     dz1 = dz2
     _ops.scale_channels(dx1[:, :dz1.shape[1]] if dx1.shape[1] != dz1.shape[1] else dx1, dz1, M, _ops.round_up(D, 8), _pad8(g1))
     d_o = _linear_backward(G, attn.proj, dz1, s["o"], M)
-    dqkv = torch.empty((M, 3 * D), dtype=F32, device=dev)
+    dqkv = torch.empty((M, 3 * D), dtype=cd, device=dev)
     T.attention_bwd(s["qkv"], s["o"], d_o, s["lse"], dqkv, B, N, H, hd, attn.scale)
     n1 = s["x"]
     if ln1 is not None:
-        n1 = n2 if ln2 is not None else _buf(M, D, dev)
+        n1 = n2 if ln2 is not None else _buf(M, D, dev, cd)
         _ops.layernorm(s["x"], n1, M, D, ln1[0], ln1[1], ln1[2])
     dn1 = _linear_backward(G, attn.qkv, dqkv, n1, M)
-    dx = _buf(M, D, dev)
+    dx = _buf(M, D, dev, cd)
     if ln1 is not None:
         G[ln1[3]] = torch.empty(D, dtype=F32, device=dev)
         G[ln1[4]] = torch.empty(D, dtype=F32, device=dev)
@@ -241,6 +246,8 @@ def _pad8(v: torch.Tensor) -> torch.Tensor:
 
 def _add(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, M: int, D: int) -> None:
     """out = a + b over [M, D] (residual_scale with a unit LayerScale)."""
+    if b.shape[1] > out.shape[1]:
+        b = b[:, :out.shape[1]]
     ones = torch.ones(D, dtype=F32, device=a.device)
     T.residual_scale(a, b, ones, out, M, D)
 
@@ -249,17 +256,18 @@ def backward_train(model, S: dict, dlogits: torch.Tensor) -> Dict[nn.Parameter, 
     """Gradients of every parameter given d(loss)/d(logits) [B, C]."""
     vt: VisionTransformer = model.vit_model
     pe: PatchEmbed = vt.patch_embed
-    B, N, M, D, has_cls = S["B"], S["N"], S["M"], S["D"], S["has_cls"]
+    B, N, M, D, has_cls, cd = S["B"], S["N"], S["M"], S["D"], S["has_cls"], S["cd"]
     dev = dlogits.device
     G: Dict[nn.Parameter, torch.Tensor] = {}
-    C = model.head.out_features
     dl = dlogits.contiguous()
+    if cd != F32:
+        dl = _ops.to_bf16(dl)
 
     # ---- head and final norm (class-token rows only)
     dnf = _linear_backward(G, model.head, dl, S["nf"], B)
     xL = S["xL"]
     ld = xL.shape[1]
-    dx = torch.zeros((M, ld), dtype=F32, device=dev)
+    dx = torch.zeros((M, ld), dtype=cd, device=dev)
     dxc = dx.view(B, N, ld)[:, 0]                          # gradient lands in the class-token rows
     fin = _ln(vt.norm_final, "VisionTransformer.norm_final")
     if fin is not None:
@@ -279,7 +287,7 @@ def backward_train(model, S: dict, dlogits: torch.Tensor) -> Dict[nn.Parameter, 
     npre = _ln(vt.norm_pre, "VisionTransformer.norm_pre")
     dxcat = dx
     if npre is not None:
-        dxcat = _buf(M, D, dev)
+        dxcat = _buf(M, D, dev, cd)
         G[npre[3]] = torch.empty(D, dtype=F32, device=dev)
         G[npre[4]] = torch.empty(D, dtype=F32, device=dev)
         T.layernorm_bwd(S["xcat"], dx, npre[0], npre[2], M, D, dxcat, dw_out=G[npre[3]], db_out=G[npre[4]])
@@ -289,7 +297,7 @@ def backward_train(model, S: dict, dlogits: torch.Tensor) -> Dict[nn.Parameter, 
     en = _ln(pe.norm_layer, "PatchEmbed.norm_layer")
     dtok = dxcat
     if en is not None:
-        dtok = _buf(M, D, dev)
+        dtok = _buf(M, D, dev, cd)
         G[en[3]] = torch.empty(D, dtype=F32, device=dev)
         G[en[4]] = torch.empty(D, dtype=F32, device=dev)
         T.layernorm_bwd(S["tok"], dxcat, en[0], en[2], M, D, dtok, dw_out=G[en[3]], db_out=G[en[4]])
@@ -308,9 +316,9 @@ def backward_train(model, S: dict, dlogits: torch.Tensor) -> Dict[nn.Parameter, 
 # ----------------------------------------------------------------------------------------------------------------
 class _VitcFunction(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, model, img, *params):
+    def forward(ctx, model, img, compute_dtype, *params):
         with torch.cuda.device(img.device):
-            logits, S = forward_train(model, img)
+            logits, S = forward_train(model, img, compute_dtype)
         ctx.model, ctx.S, ctx.params = model, S, params
         return logits
 
@@ -319,20 +327,22 @@ class _VitcFunction(torch.autograd.Function):
         with torch.cuda.device(dlogits.device):
             G = backward_train(ctx.model, ctx.S, dlogits)
         ctx.S = None
-        return (None, None) + tuple(G.get(p).reshape(p.shape) if G.get(p) is not None else None for p in ctx.params)
+        return (None, None, None) + tuple(G.get(p).reshape(p.shape) if G.get(p) is not None else None for p in ctx.params)
 
 
-def vitc_forward_with_grad(model, img: torch.Tensor) -> torch.Tensor:
-    """``model(img)`` with an autograd graph: logits whose ``backward`` fills every parameter's ``.grad``."""
+def vitc_forward_with_grad(model, img: torch.Tensor, compute_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+    """``model(img)`` with an autograd graph: fp32 logits whose ``backward`` fills every parameter's ``.grad``.
+    ``compute_dtype`` (default: the images' dtype) picks fp32 or bf16 mixed precision; parameters are fp32 in both."""
     why = supported(model)
     if why is not None:
         raise NotImplementedError(f"training path: {why}")
-    if img.dtype != F32:
-        raise TypeError("the training path is fp32 (the reference trains in fp32): pass fp32 images")
+    cd = _ops.compute_dtype(img) if compute_dtype is None else compute_dtype
+    if cd not in (F32, torch.bfloat16):
+        raise TypeError(f"compute_dtype {cd} unsupported (torch.float32 or torch.bfloat16)")
     params = [p for p in model.parameters()]
     if any(p.dtype != F32 for p in params):
-        raise TypeError("the training path needs fp32 parameters")
-    return _VitcFunction.apply(model, img, *params)
+        raise TypeError("the training path needs fp32 (master) parameters, also for bf16 compute")
+    return _VitcFunction.apply(model, img, cd, *params)
 
 
 class _CrossEntropyFunction(torch.autograd.Function):
@@ -444,15 +454,17 @@ def reference_optimizer_and_scheduler(model, total_iters: int):
 class Trainer:
     """One object for the loop body of train.py:215-224 (plus the data-parallel all-reduce)."""
 
-    def __init__(self, model, optimizer, scheduler=None, max_norm: float = 1.0, group=None):
+    def __init__(self, model, optimizer, scheduler=None, max_norm: float = 1.0, group=None,
+                 compute_dtype: Optional[torch.dtype] = None):
         self.model, self.optimizer, self.scheduler, self.max_norm, self.group = model, optimizer, scheduler, max_norm, group
+        self.compute_dtype = compute_dtype          # None: follow the images (fp32 images -> fp32, bf16 -> mixed precision)
         self.grads = FlatGradients(model.parameters())
         self.criterion = CrossEntropyLoss()
         self.last_grad_norm = None
 
     def step(self, images: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
         self.grads.zero()
-        logits = vitc_forward_with_grad(self.model, images)
+        logits = vitc_forward_with_grad(self.model, images, self.compute_dtype)
         loss = self.criterion(logits, labels)
         loss.backward()
         self.grads.all_reduce(self.group)
