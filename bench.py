@@ -113,8 +113,8 @@ def fc1_kernel_time(model, x, steps):
 
 
 def train_bench(args, world, rank, dist, dev):
-    """Informational: images/sec of the fp32 training step (the reference trains in fp32), data-parallel over the ranks
-    with the gradient all-reduce on RCCL.  Not the headline metric."""
+    """Informational: images/sec of the training step -- fp32 (the reference trains in fp32) or, with --dtype bf16,
+    mixed precision -- data-parallel over the ranks with the gradient all-reduce on RCCL.  Not the headline metric."""
     from oracle.vit_oracle import flops_per_image
     from vitm_amd import training
     from vitm_amd.sharding import max_over_ranks
@@ -123,7 +123,8 @@ def train_bench(args, world, rank, dist, dev):
     model, _ = build_model(cfg, dev)
     model = model.float().train()
     opt, sched = training.reference_optimizer_and_scheduler(model, 100000)
-    tr = training.Trainer(model, opt, sched, max_norm=1.0)
+    bf16 = args.dtype == "bf16"
+    tr = training.Trainer(model, opt, sched, max_norm=1.0, compute_dtype=torch.bfloat16 if bf16 else torch.float32)
     g = torch.Generator(device="cpu").manual_seed(4321 + rank)
     x = (torch.rand((args.batch, 3, cfg["image_size"], cfg["image_size"]), generator=g) * 2 - 1).to(dev)
     y = torch.randint(0, cfg["num_classes"], (args.batch,), generator=g).to(dev)
@@ -146,16 +147,17 @@ def train_bench(args, world, rank, dist, dev):
     if rank == 0:
         value = world * args.batch * args.steps / elapsed
         tf = value / world * 3.0 * flops_per_image(shp) / 1e12      # backward = 2x forward
+        peak = 2500.0 if bf16 else 157.0
         print(json.dumps({
-            "metric": f"images/sec, {args.config} fp32 training step", "value": round(value, 1), "unit": "images/sec",
+            "metric": f"images/sec, {args.config} {'bf16 mixed-precision' if bf16 else 'fp32'} training step", "value": round(value, 1), "unit": "images/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if bf16 else "f32", "data": "synthetic",
             "config": {"workload": f"{args.config}: forward + cross-entropy + backward + gradient all-reduce + clip + AdamW",
                        "batch_per_gpu": args.batch, "global_batch": args.batch * world,
                        "parallelism": f"data parallel x{world}, one flat-gradient all-reduce (RCCL) per step"},
-            "roofline": {"bound": "mfma", "achieved": round(tf, 1), "peak": 157.0, "unit": "TFLOP/s",
-                         "frac": round(tf / 157.0, 4), "traffic": None,
-                         "kernel": "whole step against the fp32 MFMA peak (3 x forward FLOPs)"},
+            "roofline": {"bound": "mfma", "achieved": round(tf, 1), "peak": peak, "unit": "TFLOP/s",
+                         "frac": round(tf / peak, 4), "traffic": None,
+                         "kernel": f"whole step against the dense {args.dtype} MFMA peak (3 x forward FLOPs)"},
             "final_loss": round(float(loss), 4)}), flush=True)
     if dist is not None:
         dist.barrier()
@@ -172,7 +174,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", action="store_true", help="replay the forward from a HIP graph (same kernels, one host call)")
     ap.add_argument("--mode", default="forward", choices=["forward", "train"],
-                    help="train: one fp32 training step per step (forward, loss, backward, all-reduce, clip, AdamW)")
+                    help="train: one training step per step (forward, loss, backward, all-reduce, clip, AdamW)")
+    ap.add_argument("--dtype", default=None, choices=["bf16", "f32"],
+                    help="training arithmetic (default f32, the reference's); the forward benchmark is bf16")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -189,6 +193,7 @@ def main():
     torch.cuda.set_device(dev)
 
     if args.mode == "train":
+        args.dtype = args.dtype or "f32"
         return train_bench(args, world, rank, dist, dev)
     cfg = W.CONFIGS[args.config]
     shp = W.shapes(cfg)

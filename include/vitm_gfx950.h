@@ -224,6 +224,14 @@ int vitm_attention_bwd_f32(const float* qkv, int64_t ldqkv, const float* o, int6
                            int64_t lddo, const float* lse, float* dqkv, int64_t lddqkv, float* delta, int B, int N,
                            int H, int head_dim, float scale, vitm_stream_t stream);
 
+/*
+ * vitm_attention_bwd_f32 for bf16 operands on the bf16 matrix cores (fp32 accumulation, fp32 lse / delta): qkv, o, d_o
+ * and dqkv are bf16 with leading dimensions that are multiples of 8; lse is what vitm_attention_lse wrote.
+ */
+int vitm_attention_bwd(const void* qkv, int64_t ldqkv, const void* o, int64_t ldo, const void* d_o, int64_t lddo,
+                       const float* lse, void* dqkv, int64_t lddqkv, float* delta, int B, int N, int H, int head_dim,
+                       float scale, vitm_stream_t stream);
+
 /* dst[n, m] = src[m, n] for m < M, zero for M <= m < m_pad (K padding of the weight-gradient GEMM's operands). */
 int vitm_transpose(const void* src, int64_t lds, void* dst, int64_t ldd, int dtype, int M, int N, int m_pad,
                    vitm_stream_t stream);

@@ -226,5 +226,8 @@ def test_attention_backward_bf16(T, B, N, H, hd):
     assert (lse.double() - ref_lse).abs().max().item() <= 1e-3
     dqkv = torch.full((B * N, 3 * D), float("nan"), device=DEV, dtype=BF)
     T.attention_bwd(qkv, o, d_o, lse, dqkv, B, N, H, hd, hd ** -0.5)
+    floor = 1e-3 * q64.grad.abs().max().item()          # one key: dq and dk are exactly zero in the reference
     for name, sl in (("dq", slice(0, D)), ("dk", slice(D, 2 * D)), ("dv", slice(2 * D, 3 * D))):
-        assert _rel(dqkv[:, sl], q64.grad[:, sl]) <= 2e-2, name
+        ref = q64.grad[:, sl]
+        err = (dqkv[:, sl].double() - ref).abs().max().item() / max(ref.abs().max().item(), floor)
+        assert torch.isfinite(dqkv[:, sl]).all() and err <= 2e-2, (name, err)

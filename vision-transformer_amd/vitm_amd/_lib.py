@@ -64,6 +64,8 @@ SIGNATURES = {
                                        c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "vitm_attention_lse": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int, c_int, c_int, c_int, c_float,
                                    c_void_p]),
+    "vitm_attention_bwd": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64,
+                                   c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "vitm_transpose": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p]),
     "vitm_colsum": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
     "vitm_layernorm_bwd": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_float, c_void_p, c_int64, c_void_p,

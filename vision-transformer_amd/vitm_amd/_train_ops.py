@@ -43,14 +43,10 @@ def attention_lse(qkv, out, lse, B, N, H, hd, scale) -> None:
 def attention_bwd(qkv, o, d_o, lse, dqkv, B, N, H, hd, scale) -> None:
     lib = _lib.load()
     if qkv.dtype == torch.bfloat16:
-        # bf16 activations: the backward runs on fp32 copies (fp32 products and sums), dqkv is rounded once at the end
-        q32, o32, do32 = to_f32(qkv), to_f32(o), to_f32(d_o)
-        dq32 = torch.empty(qkv.shape, dtype=F32, device=qkv.device)
-        _lib.check(lib.vitm_attention_bwd_f32(_p(q32), q32.stride(0), _p(o32), o32.stride(0), _p(do32), do32.stride(0),
-                                              _p(_f32(lse)), _p(dq32), dq32.stride(0), _p(_delta(qkv, B, H, N)), B, N, H,
-                                              hd, float(scale), _stream()), "vitm_attention_bwd_f32")
-        assert dqkv.is_contiguous()
-        _lib.check(lib.vitm_cast_f32_to_bf16(_p(dq32), _p(dqkv), dq32.numel(), _stream()), "vitm_cast_f32_to_bf16")
+        assert o.dtype == d_o.dtype == dqkv.dtype == torch.bfloat16
+        _lib.check(lib.vitm_attention_bwd(_p(qkv), qkv.stride(0), _p(o), o.stride(0), _p(d_o), d_o.stride(0), _p(_f32(lse)),
+                                          _p(dqkv), dqkv.stride(0), _p(_delta(qkv, B, H, N)), B, N, H, hd, float(scale),
+                                          _stream()), "vitm_attention_bwd")
         return
     _lib.check(lib.vitm_attention_bwd_f32(_p(_f32(qkv)), qkv.stride(0), _p(_f32(o)), o.stride(0), _p(_f32(d_o)),
                                           d_o.stride(0), _p(lse), _p(_f32(dqkv)), dqkv.stride(0), _p(_delta(qkv, B, H, N)),
