@@ -231,3 +231,22 @@ def test_attention_backward_bf16(T, B, N, H, hd):
         ref = q64.grad[:, sl]
         err = (dqkv[:, sl].double() - ref).abs().max().item() / max(ref.abs().max().item(), floor)
         assert torch.isfinite(dqkv[:, sl]).all() and err <= 2e-2, (name, err)
+
+
+@pytest.mark.parametrize("M,N,K", [(64, 128, 128), (1, 8, 8), (700, 200, 136), (12608, 768, 768), (5000, 10, 192),
+                                   (3000, 616, 192), (197 * 64, 2304, 768)])
+def test_gemm_tn(T, M, N, K):
+    """dW = a^T b straight from the row-major activations; garbage in the pad columns of a row must not leak."""
+    lda, ldb = (N + 7) // 8 * 8 + 8, (K + 7) // 8 * 8 + 16
+    a = torch.full((M, lda), float("nan"), device=DEV, dtype=BF)
+    b = torch.full((M, ldb), float("nan"), device=DEV, dtype=BF)
+    a[:, :N] = _rand(M, N, seed=51).to(BF)
+    b[:, :K] = _rand(M, K, seed=52).to(BF)
+    nr = (N + 7) // 8 * 8
+    kr = (K + 7) // 8 * 8
+    a[:, N:nr] = 0          # the 16-byte chunk that straddles the last column is read: it must hold numbers
+    b[:, K:kr] = 0
+    out = T.gemm_tn(a, b, M, N, K)
+    ref = a[:, :N].double().t() @ b[:, :K].double()
+    assert _rel(out, ref) <= 1e-5
+    assert torch.equal(out, T.gemm_tn(a, b, M, N, K)), "deterministic"

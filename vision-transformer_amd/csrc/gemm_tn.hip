@@ -1,0 +1,202 @@
+// Weight-gradient GEMM for gfx950: out[n, k] = sum_m a[m, n] * b[m, k]  (dW = dy^T x of nn.Linear's backward), bf16
+// operands, fp32 accumulation and fp32 output.
+//
+// Both operands are row-major activations whose ROWS are the reduction index, the opposite of what an MFMA fragment
+// wants (eight consecutive reduction elements per lane).  Tiles of 64 reduction rows x 128 columns of each operand are
+// staged row-major in LDS (coalesced 16-byte chunks, rows padded by 16 bytes) and the fragments are fetched with
+// ds_read_b64_tr_b16, the transposing LDS read: no transposed copy of an activation is ever written to HBM.
+//
+// The output is small (a weight matrix) and the reduction is long (every token of the batch), so the reduction is split
+// over gridDim.y workgroup slices: each slice writes its own fp32 partial tile and a second kernel adds the slices in a
+// fixed order (deterministic; no atomics).  Workgroup = 4 waves, 128 x 128 output tile, 64 x 64 per wave as 2 x 2
+// v_mfma_f32_32x32x16_bf16 tiles; global loads of the next 64 rows are in flight while the current ones are multiplied
+// (register staging, two LDS buffers, one barrier per step).
+#include "common.h"
+
+namespace {
+
+constexpr int TN_BN = 128;            // output rows (columns of a) per workgroup
+constexpr int TN_BK = 128;            // output columns (columns of b) per workgroup
+constexpr int TN_BM = 64;             // reduction rows per step
+constexpr int TN_RS = TN_BN * 2 + 16; // LDS row stride in bytes
+constexpr int TN_TILE = TN_BM * TN_RS;
+constexpr int TN_TARGET_WGS = 768;    // workgroups wanted in flight (256 CUs x 2 resident + slack)
+constexpr int TN_MIN_ROWS = 512;      // reduction rows a slice should at least own
+
+__device__ __forceinline__ u16x4_t tn_tr_read(const char* lds_addr) {
+  s16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(lds_addr));
+  return __builtin_bit_cast(u16x4_t, v);
+}
+
+__device__ __forceinline__ bf16x8_t tn_frag(const char* a0) {
+  const u16x4_t lo = tn_tr_read(a0);
+  const u16x4_t hi = tn_tr_read(a0 + 8 * TN_RS);
+  u16x8_t t;
+  t[0] = lo[0]; t[1] = lo[1]; t[2] = lo[2]; t[3] = lo[3];
+  t[4] = hi[0]; t[5] = hi[1]; t[6] = hi[2]; t[7] = hi[3];
+  return __builtin_bit_cast(bf16x8_t, t);
+}
+
+__global__ __launch_bounds__(256) void gemm_tn_kernel(const bf16_t* __restrict__ a, int64_t lda,
+                                                      const bf16_t* __restrict__ b, int64_t ldb,
+                                                      float* __restrict__ dst, int64_t ldd, int64_t slice_stride, int M,
+                                                      int N, int K, int rows_per_slice, int tiles_k) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 buffers][a tile, b tile]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, hh = lane >> 5;
+  const int tn = blockIdx.x / tiles_k, tk = blockIdx.x - tn * tiles_k;
+  const int n0 = tn * TN_BN, k0 = tk * TN_BK;
+  const int m_begin = blockIdx.y * rows_per_slice;
+  int m_end = m_begin + rows_per_slice;
+  m_end = m_end < M ? m_end : M;
+  const int nsteps = (m_end - m_begin + TN_BM - 1) / TN_BM;
+
+  // staging: 1024 16-byte chunks per operand tile, four per thread
+  const int srow = tid >> 4, sch = tid & 15;            // + 16 rows per j
+  const bool a_ok = n0 + sch * 8 < N, b_ok = k0 + sch * 8 < K;
+  const bf16_t* ap = a + (int64_t)(m_begin + srow) * lda + n0 + sch * 8;
+  const bf16_t* bp = b + (int64_t)(m_begin + srow) * ldb + k0 + sch * 8;
+  const int soff = srow * TN_RS + sch * 16;
+  uint4 ra[4], rb[4];
+  auto fetch = [&](int step) {
+    const int mrow = m_begin + step * TN_BM + srow;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const bool in = mrow + 16 * j < m_end;
+      const int64_t ro = (int64_t)(step * TN_BM + 16 * j);
+      ra[j] = (in && a_ok) ? *(const uint4*)(ap + ro * lda) : make_uint4(0, 0, 0, 0);
+      rb[j] = (in && b_ok) ? *(const uint4*)(bp + ro * ldb) : make_uint4(0, 0, 0, 0);
+    }
+  };
+  auto stash = [&](int buf) {
+    char* As = smem + buf * 2 * TN_TILE;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      *(uint4*)(As + soff + 16 * j * TN_RS) = ra[j];
+      *(uint4*)(As + TN_TILE + soff + 16 * j * TN_RS) = rb[j];
+    }
+  };
+
+  f32x16_t acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int g16 = lane >> 4, li = lane & 15;
+  const int tr_off = (4 * hh + (li >> 2)) * TN_RS + (16 * (g16 & 1) + 4 * (li & 3)) * 2;
+  const int wn = wave >> 1, wk = wave & 1;
+  const int a_off = tr_off + (64 * wn) * 2, b_off = TN_TILE + tr_off + (64 * wk) * 2;
+
+  if (nsteps > 0) {
+    fetch(0);
+    stash(0);
+  }
+  __syncthreads();
+  for (int step = 0; step < nsteps; ++step) {
+    const bool more = step + 1 < nsteps;
+    if (more) fetch(step + 1);
+    const char* base = smem + (step & 1) * 2 * TN_TILE;
+#pragma unroll
+    for (int s2 = 0; s2 < TN_BM / 16; ++s2) {
+      const char* t = base + 16 * s2 * TN_RS;
+      const bf16x8_t a0 = tn_frag(t + a_off), a1 = tn_frag(t + a_off + 64);
+      const bf16x8_t b0 = tn_frag(t + b_off), b1 = tn_frag(t + b_off + 64);
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+    }
+    if (more) stash((step + 1) & 1);
+    __syncthreads();
+  }
+
+  float* out = dst + (int64_t)blockIdx.y * slice_stride;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int kc = k0 + 64 * wk + 32 * j + r;
+      if (kc >= K) continue;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int n = n0 + 64 * wn + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * hh;
+        if (n < N) out[(int64_t)n * ldd + kc] = acc[i][j][e];
+      }
+    }
+}
+
+// out[n, k] = sum over slices, in slice order
+__global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict__ part, int64_t slice_stride, int slices,
+                                                        float* __restrict__ out, int64_t ldo, int N, int K) {
+  const int64_t total = (int64_t)N * K;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    float s = part[i];
+    for (int sl = 1; sl < slices; ++sl) s += part[i + sl * slice_stride];
+    const int64_t n = i / K;
+    out[n * ldo + (i - n * K)] = s;
+  }
+}
+
+struct TnPlan {
+  int tiles_n, tiles_k, slices, rows_per_slice;
+};
+TnPlan tn_plan(int M, int N, int K) {
+  TnPlan p;
+  p.tiles_n = (N + TN_BN - 1) / TN_BN;
+  p.tiles_k = (K + TN_BK - 1) / TN_BK;
+  const int64_t tiles = (int64_t)p.tiles_n * p.tiles_k;
+  int64_t s = (TN_TARGET_WGS + tiles - 1) / tiles;
+  const int64_t smax = (M + TN_MIN_ROWS - 1) / TN_MIN_ROWS;
+  s = s > smax ? smax : s;
+  s = s < 1 ? 1 : (s > 64 ? 64 : s);
+  int rps = (int)((M + s - 1) / s);
+  rps = (rps + TN_BM - 1) / TN_BM * TN_BM;
+  p.rows_per_slice = rps;
+  p.slices = (M + rps - 1) / rps;
+  return p;
+}
+
+}  // namespace
+
+extern "C" int64_t vitm_gemm_tn_workspace_floats(int M, int N, int K) {
+  if (M <= 0 || N <= 0 || K <= 0) return 0;
+  const TnPlan p = tn_plan(M, N, K);
+  return p.slices > 1 ? (int64_t)p.slices * N * K : 0;
+}
+
+extern "C" int vitm_gemm_tn(const void* a, int64_t lda, const void* b, int64_t ldb, float* out, int64_t ldo, int M, int N,
+                            int K, float* workspace, int64_t workspace_floats, vitm_stream_t stream) {
+  VITM_REQUIRE(a && b && out, "vitm_gemm_tn: null pointer");
+  VITM_REQUIRE(M > 0 && N > 0 && K > 0, "vitm_gemm_tn: M, N, K must be positive");
+  VITM_REQUIRE(lda >= N && ldb >= K && ldo >= K && lda % 8 == 0 && ldb % 8 == 0,
+               "vitm_gemm_tn: lda >= N, ldb >= K (both multiples of 8), ldo >= K");
+  VITM_REQUIRE((((uintptr_t)a | (uintptr_t)b) & 15) == 0, "vitm_gemm_tn: operands must be 16-byte aligned");
+  const TnPlan p = tn_plan(M, N, K);
+  VITM_REQUIRE((int64_t)p.tiles_n * p.tiles_k < (1ll << 31), "vitm_gemm_tn: grid too large for one launch");
+  const int64_t need = p.slices > 1 ? (int64_t)p.slices * N * K : 0;
+  VITM_REQUIRE(need == 0 || (workspace && workspace_floats >= need),
+               "vitm_gemm_tn: workspace of %lld floats needed (vitm_gemm_tn_workspace_floats)", (long long)need);
+  hipStream_t st = (hipStream_t)stream;
+  auto kfn = gemm_tn_kernel;
+  VITM_LDS_OPTIN(kfn, 4 * TN_TILE, "vitm_gemm_tn");
+  const dim3 grid((unsigned)(p.tiles_n * p.tiles_k), (unsigned)p.slices);
+  if (p.slices == 1) {
+    hipLaunchKernelGGL(kfn, grid, dim3(256), 4 * TN_TILE, st, (const bf16_t*)a, lda, (const bf16_t*)b, ldb, out, ldo,
+                       (int64_t)0, M, N, K, p.rows_per_slice, p.tiles_k);
+    VITM_CHECK_LAUNCH("vitm_gemm_tn");
+    return VITM_OK;
+  }
+  hipLaunchKernelGGL(kfn, grid, dim3(256), 4 * TN_TILE, st, (const bf16_t*)a, lda, (const bf16_t*)b, ldb, workspace,
+                     (int64_t)K, (int64_t)N * K, M, N, K, p.rows_per_slice, p.tiles_k);
+  VITM_CHECK_LAUNCH("vitm_gemm_tn");
+  const int64_t total = (int64_t)N * K;
+  int64_t g = (total + 255) / 256;
+  g = g > 4096 ? 4096 : g;
+  hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)g), dim3(256), 0, st, (const float*)workspace, (int64_t)N * K,
+                     p.slices, out, ldo, N, K);
+  VITM_CHECK_LAUNCH("vitm_gemm_tn");
+  return VITM_OK;
+}

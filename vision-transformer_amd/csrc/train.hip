@@ -21,6 +21,29 @@ __device__ __forceinline__ float ldv(const float* p) { return *p; }
 __device__ __forceinline__ float ldv(const bf16_t* p) { return bf2f(*p); }
 __device__ __forceinline__ void stv(float* p, float v) { *p = v; }
 __device__ __forceinline__ void stv(bf16_t* p, float v) { *p = f2bf(v); }
+// eight consecutive elements as fp32 (one 16-byte access for bf16, two for fp32); p is 16-byte aligned
+__device__ __forceinline__ void ld8(const float* p, float (&v)[8]) {
+  const float4 a = *(const float4*)p, b = *(const float4*)(p + 4);
+  v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+__device__ __forceinline__ void ld8(const bf16_t* p, float (&v)[8]) {
+  const u16x8_t t = *(const u16x8_t*)p;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = bf2f(t[e]);
+}
+__device__ __forceinline__ void st8(float* p, const float (&v)[8]) {
+  *(float4*)p = make_float4(v[0], v[1], v[2], v[3]);
+  *(float4*)(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+}
+__device__ __forceinline__ void st8(bf16_t* p, const float (&v)[8]) {
+  uint4 w;
+  w.x = pack_bf2(v[0], v[1]); w.y = pack_bf2(v[2], v[3]); w.z = pack_bf2(v[4], v[5]); w.w = pack_bf2(v[6], v[7]);
+  *(uint4*)p = w;
+}
+template <typename T>
+inline bool vec_ok(const void* p, int64_t ld) {   // rows start 16-byte aligned
+  return p == nullptr || ((((uintptr_t)p) & 15) == 0 && (ld * (int64_t)sizeof(T)) % 16 == 0);
+}
 inline unsigned stream_grid(int64_t items, int per = 256, int cap = 4096) {
   int64_t g = (items + per - 1) / per;
   return (unsigned)(g < 1 ? 1 : (g > cap ? cap : g));
@@ -68,6 +91,48 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ a, in
   sh[rl][threadIdx.x & 63] = s;
   __syncthreads();
   if (rl == 0 && col < D) out[(int64_t)blockIdx.y * ldo + col] = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
+}
+
+// vector form: a thread owns 8 adjacent columns (D % 8 == 0, rows 16-byte aligned); workgroup = 32 column groups x 8
+// row lanes, so a workgroup covers 256 columns; blockIdx.y = row chunk
+template <typename T>
+__global__ __launch_bounds__(256) void colsum8_kernel(const T* __restrict__ a, int64_t lda, const T* __restrict__ b,
+                                                      int64_t ldb, float* __restrict__ out, int64_t ldo, int M, int D,
+                                                      int rows_per_chunk) {
+  __shared__ float sh[8][32][9];
+  const int cg = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int col = (blockIdx.x * 32 + cg) * 8;
+  const int r0 = blockIdx.y * rows_per_chunk;
+  int r1 = r0 + rows_per_chunk;
+  r1 = r1 < M ? r1 : M;
+  float s[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) s[e] = 0.f;
+  if (col < D) {
+    for (int m = r0 + rl; m < r1; m += 8) {
+      float av[8];
+      ld8(a + (int64_t)m * lda + col, av);
+      if (b) {
+        float bv[8];
+        ld8(b + (int64_t)m * ldb + col, bv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s[e] = fmaf(av[e], bv[e], s[e]);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s[e] += av[e];
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) sh[rl][cg][e] = s[e];
+  __syncthreads();
+  // 256 threads = 256 columns of this workgroup
+  const int c = threadIdx.x, g = c >> 3, e = c & 7;
+  const int oc = blockIdx.x * 256 + c;
+  if (oc < D) {
+    float t = ((sh[0][g][e] + sh[1][g][e]) + (sh[2][g][e] + sh[3][g][e])) + ((sh[4][g][e] + sh[5][g][e]) + (sh[6][g][e] + sh[7][g][e]));
+    out[(int64_t)blockIdx.y * ldo + oc] = t;
+  }
 }
 
 // ---- LayerNorm backward: one wave per row at a time, a workgroup of 4 waves strides over the rows ------------------
@@ -165,6 +230,164 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
         dbp[(int64_t)blockIdx.x * D + c + e] = (red[1][0][i] + red[1][1][i]) + (red[1][2][i] + red[1][3][i]);
       }
     }
+  }
+}
+
+// Fast form: rows 16-byte aligned, NC = ceil(D / 512) chunks of 8 columns per lane (registers sized to the row), 16-byte
+// accesses, enough workgroups in flight to hide the row-to-row latency.
+template <typename T, int NC>
+__global__ __launch_bounds__(256) void layernorm_bwd8_kernel(const T* __restrict__ x, int64_t ldx,
+                                                             const T* __restrict__ dy, int64_t lddy,
+                                                             const float* __restrict__ w, float eps,
+                                                             const T* __restrict__ dx_add, int64_t ldadd,
+                                                             T* __restrict__ dx, int64_t lddx,
+                                                             float* __restrict__ dwp, float* __restrict__ dbp, int M, int D) {
+  __shared__ float red[2][4][64 * 8];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float wv[NC][8], gw[NC][8], gb[NC][8];
+#pragma unroll
+  for (int t = 0; t < NC; ++t) {
+    const int c = (lane + 64 * t) * 8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      wv[t][e] = c < D ? w[c + e] : 0.f;
+      gw[t][e] = 0.f;
+      gb[t][e] = 0.f;
+    }
+  }
+  const float inv_d = 1.0f / (float)D;
+  for (int m = blockIdx.x * 4 + wave; m < M; m += gridDim.x * 4) {
+    float xv[NC][8], gv[NC][8];
+    float s = 0.f;
+#pragma unroll
+    for (int t = 0; t < NC; ++t) {
+      const int c = (lane + 64 * t) * 8;
+      if (c < D) {
+        ld8(x + (int64_t)m * ldx + c, xv[t]);
+        ld8(dy + (int64_t)m * lddy + c, gv[t]);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) xv[t][e] = gv[t][e] = 0.f;
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s += xv[t][e];
+    }
+    const float mean = wave_sum(s) * inv_d;
+    float q = 0.f;
+#pragma unroll
+    for (int t = 0; t < NC; ++t)
+      if ((lane + 64 * t) * 8 < D) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) q = fmaf(xv[t][e] - mean, xv[t][e] - mean, q);
+      }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) * inv_d + eps);
+    float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+    for (int t = 0; t < NC; ++t)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {          // columns past D hold zeros: they add nothing
+        const float xh = (xv[t][e] - mean) * rstd;
+        const float g = gv[t][e] * wv[t][e];
+        gw[t][e] = fmaf(gv[t][e], xh, gw[t][e]);
+        gb[t][e] += gv[t][e];
+        xv[t][e] = xh;
+        gv[t][e] = g;
+        c1 += g;
+        c2 = fmaf(g, xh, c2);
+      }
+    c1 = wave_sum(c1) * inv_d;
+    c2 = wave_sum(c2) * inv_d;
+#pragma unroll
+    for (int t = 0; t < NC; ++t) {
+      const int c = (lane + 64 * t) * 8;
+      if (c < D) {
+        float rr[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) rr[e] = rstd * (gv[t][e] - c1 - xv[t][e] * c2);
+        if (dx_add) {
+          float av[8];
+          ld8(dx_add + (int64_t)m * ldadd + c, av);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) rr[e] += av[e];
+        }
+        st8(dx + (int64_t)m * lddx + c, rr);
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < NC; ++t) {
+    const int c = (lane + 64 * t) * 8;
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      red[0][wave][lane * 8 + e] = gw[t][e];
+      red[1][wave][lane * 8 + e] = gb[t][e];
+    }
+    __syncthreads();
+    if (wave == 0 && c < D) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int i = lane * 8 + e;
+        dwp[(int64_t)blockIdx.x * D + c + e] = (red[0][0][i] + red[0][1][i]) + (red[0][2][i] + red[0][3][i]);
+        dbp[(int64_t)blockIdx.x * D + c + e] = (red[1][0][i] + red[1][1][i]) + (red[1][2][i] + red[1][3][i]);
+      }
+    }
+  }
+}
+
+template <typename T>
+void launch_ln_bwd(const void* x, int64_t ldx, const void* dy, int64_t lddy, const float* w, float eps, const void* dx_add,
+                   int64_t ldadd, void* dx, int64_t lddx, float* dwp, float* dbp, int nblocks, int M, int D, hipStream_t st) {
+  const T *xp = (const T*)x, *gp = (const T*)dy, *ap = (const T*)dx_add;
+  T* op = (T*)dx;
+  const dim3 grid((unsigned)nblocks), blk(256);
+  if (vec_ok<T>(x, ldx) && vec_ok<T>(dy, lddy) && vec_ok<T>(dx_add, ldadd) && vec_ok<T>(dx, lddx)) {
+    const int nc = (D + 511) / 512;
+#define VITM_LNB(NCV) hipLaunchKernelGGL((layernorm_bwd8_kernel<T, NCV>), grid, blk, 0, st, xp, ldx, gp, lddy, w, eps, ap, ldadd, op, lddx, dwp, dbp, M, D)
+    if (nc == 1) VITM_LNB(1);
+    else if (nc == 2) VITM_LNB(2);
+    else if (nc == 3) VITM_LNB(3);
+    else VITM_LNB(4);
+#undef VITM_LNB
+    return;
+  }
+  hipLaunchKernelGGL(layernorm_bwd_kernel<T>, grid, blk, 0, st, xp, ldx, gp, lddy, w, eps, ap, ldadd, op, lddx, dwp, dbp, M, D);
+}
+
+// ---- GELU backward: eight elements per thread when the rows allow 16-byte accesses ---------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void gelu_bwd8_kernel(const T* __restrict__ pre, int64_t ldp, const T* __restrict__ dh,
+                                                        int64_t ldh, T* __restrict__ dpre, int64_t ldd, int M, int D8) {
+  const int64_t total = (int64_t)M * D8;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t m = i / D8;
+    const int c = (int)(i - m * D8) * 8;
+    float v[8], g[8];
+    ld8(pre + m * ldp + c, v);
+    ld8(dh + m * ldh + c, g);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float cdf = 0.5f * (1.0f + erf_as(v[e] * 0.70710678118654752f));
+      const float pdf = 0.3989422804014327f * __expf(-0.5f * v[e] * v[e]);
+      g[e] *= fmaf(v[e], pdf, cdf);
+    }
+    st8(dpre + m * ldd + c, g);
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void residual_scale8_kernel(const T* __restrict__ r, int64_t ldr, const T* __restrict__ z,
+                                                              int64_t ldz, const float* __restrict__ g, T* __restrict__ out,
+                                                              int64_t ldo, int M, int D8) {
+  const int64_t total = (int64_t)M * D8;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t m = i / D8;
+    const int c = (int)(i - m * D8) * 8;
+    float rv[8], zv[8];
+    ld8(r + m * ldr + c, rv);
+    ld8(z + m * ldz + c, zv);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) rv[e] = fmaf(g[c + e], zv[e], rv[e]);
+    st8(out + m * ldo + c, rv);
   }
 }
 
@@ -297,9 +520,18 @@ extern "C" int vitm_colsum(const void* a, int64_t lda, const void* b, int64_t ld
   VITM_REQUIRE(M > 0 && D > 0 && nchunks > 0 && nchunks < 65536 && lda >= D && ldo >= D && (!b || ldb >= D),
                "vitm_colsum: bad shape");
   const int rpc = (M + nchunks - 1) / nchunks;
-  const dim3 grid((unsigned)((D + 63) / 64), (unsigned)nchunks);
-  if (dtype == VITM_F32) hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)a, lda, (const float*)b, ldb, out, ldo, M, D, rpc);
-  else hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)a, lda, (const bf16_t*)b, ldb, out, ldo, M, D, rpc);
+  hipStream_t st = (hipStream_t)stream;
+  const bool f32 = dtype == VITM_F32;
+  const bool vec = D % 8 == 0 && (f32 ? vec_ok<float>(a, lda) && vec_ok<float>(b, ldb) : vec_ok<bf16_t>(a, lda) && vec_ok<bf16_t>(b, ldb));
+  if (vec) {
+    const dim3 grid((unsigned)((D + 255) / 256), (unsigned)nchunks);
+    if (f32) hipLaunchKernelGGL(colsum8_kernel<float>, grid, dim3(256), 0, st, (const float*)a, lda, (const float*)b, ldb, out, ldo, M, D, rpc);
+    else hipLaunchKernelGGL(colsum8_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)a, lda, (const bf16_t*)b, ldb, out, ldo, M, D, rpc);
+  } else {
+    const dim3 grid((unsigned)((D + 63) / 64), (unsigned)nchunks);
+    if (f32) hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, st, (const float*)a, lda, (const float*)b, ldb, out, ldo, M, D, rpc);
+    else hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)a, lda, (const bf16_t*)b, ldb, out, ldo, M, D, rpc);
+  }
   VITM_CHECK_LAUNCH("vitm_colsum");
   return VITM_OK;
 }
@@ -311,12 +543,8 @@ extern "C" int vitm_layernorm_bwd(const void* x, int64_t ldx, const void* dy, in
   VITM_REQUIRE(dtype == VITM_BF16 || dtype == VITM_F32, "vitm_layernorm_bwd: bad dtype %d", dtype);
   VITM_REQUIRE(M > 0 && D > 0 && D % 8 == 0 && D <= 64 * 8 * LN_MAXC, "vitm_layernorm_bwd: D=%d must be a multiple of 8 and <= %d", D, 64 * 8 * LN_MAXC);
   VITM_REQUIRE(ldx >= D && lddy >= D && lddx >= D && (!dx_add || ldadd >= D) && nblocks > 0, "vitm_layernorm_bwd: bad leading dimension");
-  if (dtype == VITM_F32)
-    hipLaunchKernelGGL(layernorm_bwd_kernel<float>, dim3((unsigned)nblocks), dim3(256), 0, (hipStream_t)stream, (const float*)x, ldx, (const float*)dy, lddy, w, eps,
-                       (const float*)dx_add, ldadd, (float*)dx, lddx, dw_partial, db_partial, M, D);
-  else
-    hipLaunchKernelGGL(layernorm_bwd_kernel<bf16_t>, dim3((unsigned)nblocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, (const bf16_t*)dy, lddy, w, eps,
-                       (const bf16_t*)dx_add, ldadd, (bf16_t*)dx, lddx, dw_partial, db_partial, M, D);
+  if (dtype == VITM_F32) launch_ln_bwd<float>(x, ldx, dy, lddy, w, eps, dx_add, ldadd, dx, lddx, dw_partial, db_partial, nblocks, M, D, (hipStream_t)stream);
+  else launch_ln_bwd<bf16_t>(x, ldx, dy, lddy, w, eps, dx_add, ldadd, dx, lddx, dw_partial, db_partial, nblocks, M, D, (hipStream_t)stream);
   VITM_CHECK_LAUNCH("vitm_layernorm_bwd");
   return VITM_OK;
 }
@@ -326,9 +554,19 @@ extern "C" int vitm_gelu_bwd(const void* pre, int64_t ldp, const void* dh, int64
   VITM_REQUIRE(pre && dh && dpre, "vitm_gelu_bwd: null pointer");
   VITM_REQUIRE(dtype == VITM_BF16 || dtype == VITM_F32, "vitm_gelu_bwd: bad dtype %d", dtype);
   VITM_REQUIRE(M > 0 && D > 0 && ldp >= D && ldh >= D && ldd >= D, "vitm_gelu_bwd: bad shape");
-  const dim3 grid(stream_grid((int64_t)M * D));
-  if (dtype == VITM_F32) hipLaunchKernelGGL(gelu_bwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)pre, ldp, (const float*)dh, ldh, (float*)dpre, ldd, M, D);
-  else hipLaunchKernelGGL(gelu_bwd_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)pre, ldp, (const bf16_t*)dh, ldh, (bf16_t*)dpre, ldd, M, D);
+  hipStream_t st = (hipStream_t)stream;
+  const bool f32 = dtype == VITM_F32;
+  const bool vec = D % 8 == 0 && (f32 ? vec_ok<float>(pre, ldp) && vec_ok<float>(dh, ldh) && vec_ok<float>(dpre, ldd)
+                                      : vec_ok<bf16_t>(pre, ldp) && vec_ok<bf16_t>(dh, ldh) && vec_ok<bf16_t>(dpre, ldd));
+  if (vec) {
+    const dim3 grid(stream_grid((int64_t)M * (D / 8), 256, 8192));
+    if (f32) hipLaunchKernelGGL(gelu_bwd8_kernel<float>, grid, dim3(256), 0, st, (const float*)pre, ldp, (const float*)dh, ldh, (float*)dpre, ldd, M, D / 8);
+    else hipLaunchKernelGGL(gelu_bwd8_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)pre, ldp, (const bf16_t*)dh, ldh, (bf16_t*)dpre, ldd, M, D / 8);
+  } else {
+    const dim3 grid(stream_grid((int64_t)M * D));
+    if (f32) hipLaunchKernelGGL(gelu_bwd_kernel<float>, grid, dim3(256), 0, st, (const float*)pre, ldp, (const float*)dh, ldh, (float*)dpre, ldd, M, D);
+    else hipLaunchKernelGGL(gelu_bwd_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)pre, ldp, (const bf16_t*)dh, ldh, (bf16_t*)dpre, ldd, M, D);
+  }
   VITM_CHECK_LAUNCH("vitm_gelu_bwd");
   return VITM_OK;
 }
@@ -338,9 +576,19 @@ extern "C" int vitm_residual_scale(const void* resid, int64_t ldr, const void* z
   VITM_REQUIRE(resid && z && gamma && out, "vitm_residual_scale: null pointer");
   VITM_REQUIRE(dtype == VITM_BF16 || dtype == VITM_F32, "vitm_residual_scale: bad dtype %d", dtype);
   VITM_REQUIRE(M > 0 && D > 0 && ldr >= D && ldz >= D && ldo >= D, "vitm_residual_scale: bad shape");
-  const dim3 grid(stream_grid((int64_t)M * D));
-  if (dtype == VITM_F32) hipLaunchKernelGGL(residual_scale_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)resid, ldr, (const float*)z, ldz, gamma, (float*)out, ldo, M, D);
-  else hipLaunchKernelGGL(residual_scale_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)resid, ldr, (const bf16_t*)z, ldz, gamma, (bf16_t*)out, ldo, M, D);
+  hipStream_t st = (hipStream_t)stream;
+  const bool f32 = dtype == VITM_F32;
+  const bool vec = D % 8 == 0 && (f32 ? vec_ok<float>(resid, ldr) && vec_ok<float>(z, ldz) && vec_ok<float>(out, ldo)
+                                      : vec_ok<bf16_t>(resid, ldr) && vec_ok<bf16_t>(z, ldz) && vec_ok<bf16_t>(out, ldo));
+  if (vec) {
+    const dim3 grid(stream_grid((int64_t)M * (D / 8), 256, 8192));
+    if (f32) hipLaunchKernelGGL(residual_scale8_kernel<float>, grid, dim3(256), 0, st, (const float*)resid, ldr, (const float*)z, ldz, gamma, (float*)out, ldo, M, D / 8);
+    else hipLaunchKernelGGL(residual_scale8_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)resid, ldr, (const bf16_t*)z, ldz, gamma, (bf16_t*)out, ldo, M, D / 8);
+  } else {
+    const dim3 grid(stream_grid((int64_t)M * D));
+    if (f32) hipLaunchKernelGGL(residual_scale_kernel<float>, grid, dim3(256), 0, st, (const float*)resid, ldr, (const float*)z, ldz, gamma, (float*)out, ldo, M, D);
+    else hipLaunchKernelGGL(residual_scale_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)resid, ldr, (const bf16_t*)z, ldz, gamma, (bf16_t*)out, ldo, M, D);
+  }
   VITM_CHECK_LAUNCH("vitm_residual_scale");
   return VITM_OK;
 }

@@ -12,7 +12,7 @@ from . import _lib
 from ._ops import _p, _dt, _stream, round_up, k_multiple, pack_linear, gemm, to_f32, to_bf16, EPI_BIAS
 
 COLSUM_CHUNKS = 64
-LN_BWD_BLOCKS = 256
+LN_BWD_BLOCKS = 1024
 F32 = torch.float32
 
 
@@ -72,7 +72,7 @@ def colsum(a: torch.Tensor, M: int, D: int, b: Optional[torch.Tensor] = None, ou
     if out is None:
         out = torch.empty(D, dtype=F32, device=a.device)
     dt = _rm(a) if b is None else _rm(a, b)
-    nch = min(COLSUM_CHUNKS, M)
+    nch = min(COLSUM_CHUNKS, M // 16) if M >= 32 else 1      # short inputs: one stage
     ldb = 0 if b is None else b.stride(0)
     if nch > 1:
         part = torch.empty((nch, D), dtype=F32, device=a.device)
@@ -152,9 +152,28 @@ def linear_dx(dy: torch.Tensor, weight: torch.Tensor, M: int, out: Optional[torc
     return out
 
 
+def _tn_ok(t: torch.Tensor) -> bool:
+    return t.stride(1) == 1 and t.stride(0) % 8 == 0 and t.data_ptr() % 16 == 0
+
+
+def gemm_tn(a: torch.Tensor, b: torch.Tensor, M: int, N: int, K: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[N, K] (fp32) = a[:M, :N]^T . b[:M, :K] for bf16 row-major a, b: no transposed copies, reduction split over
+    workgroup slices and summed in a fixed order."""
+    lib = _lib.load()
+    if out is None:
+        out = torch.empty((N, K), dtype=F32, device=a.device)
+    nws = lib.vitm_gemm_tn_workspace_floats(M, N, K)
+    ws = torch.empty(nws, dtype=F32, device=a.device) if nws else None
+    _lib.check(lib.vitm_gemm_tn(_p(a), a.stride(0), _p(b), b.stride(0), _p(out), out.stride(0), M, N, K, _p(ws), nws,
+                                _stream()), "vitm_gemm_tn")
+    return out
+
+
 def linear_dw(dy: torch.Tensor, x: torch.Tensor, M: int, N: int, K: int) -> torch.Tensor:
     """dW[N, K] (fp32) = dy[:, :N]^T . x[:, :K]: the forward GEMM on the two transposed activations (rows padded to
     its K multiple); bf16 operands accumulate and store in fp32."""
+    if dy.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and _tn_ok(dy) and _tn_ok(x):
+        return gemm_tn(dy, x, M, N, K)
     mp = round_up(M, k_multiple())
     dyt = transpose(dy, M, N, mp)                                   # [N, mp]
     xt = transpose(x, M, K, mp)                                     # [K, mp]

@@ -113,7 +113,7 @@ def _block_forward(blk: Block, x: torch.Tensor, B: int, N: int) -> (torch.Tensor
     _ops.gemm(h, _pk(mlp.linear_layer2.weight, mlp.linear_layer2.bias, cd), z2, _ops.EPI_BIAS, M)
     x2 = _buf(M, D, dev, cd)
     T.residual_scale(x1, z2, _ops.f32vec(blk.ls2.gamma), x2, M, D)
-    s.update(qkv=qkv, o=o, lse=lse, z1=z1, x1=x1, pre=pre, z2=z2)
+    s.update(qkv=qkv, o=o, lse=lse, z1=z1, x1=x1, pre=pre, h=h, z2=z2)
     return x2, s
 
 
@@ -194,10 +194,8 @@ def _block_backward(G: Dict, blk: Block, s: dict, dx2: torch.Tensor, B: int, N: 
     G[blk.ls2.gamma] = T.colsum(dx2, M, D, s["z2"])
     dz2 = torch.empty((M, _ops.round_up(D, 8)), dtype=cd, device=dev)
     _ops.scale_channels(dx2[:, :dz2.shape[1]] if dx2.shape[1] != dz2.shape[1] else dx2, dz2, M, _ops.round_up(D, 8), _pad8(g2))
-    h = _buf(M, hid, dev, cd)
-    _ops.gelu(s["pre"], h, M, _ops.round_up(hid, 8))
-    dh = _linear_backward(G, mlp.linear_layer2, dz2, h, M)
-    dpre = h                                              # reuse: h is dead after the weight gradient
+    dh = _linear_backward(G, mlp.linear_layer2, dz2, s["h"], M)
+    dpre = dh                                             # in place: element-wise
     T.gelu_bwd(s["pre"], dh, dpre, M, hid)
     n2 = s["x1"]
     if ln2 is not None:
