@@ -242,9 +242,12 @@ int vitm_gemm_tn(const void* a, int64_t lda, const void* b, int64_t ldb, float* 
                  float* workspace, int64_t workspace_floats, vitm_stream_t stream);
 int64_t vitm_gemm_tn_workspace_floats(int M, int N, int K);
 
-/* dst[n, m] = src[m, n] for m < M, zero for M <= m < m_pad (K padding of the weight-gradient GEMM's operands). */
-int vitm_transpose(const void* src, int64_t lds, void* dst, int64_t ldd, int dtype, int M, int N, int m_pad,
-                   vitm_stream_t stream);
+/*
+ * dst[n, m] = src[m, n] for m < M, zero for M <= m < m_pad (K padding of a GEMM operand), converting src_dtype to
+ * dst_dtype on the way: W^T of an fp32 master weight as the bf16 operand of the input-gradient GEMM in one pass.
+ */
+int vitm_transpose(const void* src, int src_dtype, int64_t lds, void* dst, int dst_dtype, int64_t ldd, int M, int N,
+                   int m_pad, vitm_stream_t stream);
 
 /*
  * out[c, d] = sum over the rows m of chunk c (nchunks equal chunks of the M rows) of a[m, d] * (b ? b[m, d] : 1).

@@ -3,14 +3,14 @@
 //
 // Both operands are row-major activations whose ROWS are the reduction index, the opposite of what an MFMA fragment
 // wants (eight consecutive reduction elements per lane).  Tiles of 64 reduction rows x 128 columns of each operand are
-// staged row-major in LDS (coalesced 16-byte chunks, rows padded by 16 bytes) and the fragments are fetched with
+// staged row-major in LDS (coalesced 16-byte chunks, rows padded by 64 bytes) and the fragments are fetched with
 // ds_read_b64_tr_b16, the transposing LDS read: no transposed copy of an activation is ever written to HBM.
 //
 // The output is small (a weight matrix) and the reduction is long (every token of the batch), so the reduction is split
-// over gridDim.y workgroup slices: each slice writes its own fp32 partial tile and a second kernel adds the slices in a
+// over workgroup slices: each slice writes its own fp32 partial tile and a second kernel adds the slices in a
 // fixed order (deterministic; no atomics).  Workgroup = 4 waves, 128 x 128 output tile, 64 x 64 per wave as 2 x 2
-// v_mfma_f32_32x32x16_bf16 tiles; global loads of the next 64 rows are in flight while the current ones are multiplied
-// (register staging, two LDS buffers, one barrier per step).
+// v_mfma_f32_32x32x16_bf16 tiles; the global loads of the next two 64-row steps are in flight while the current one is
+// multiplied (two register sets, two LDS buffers, one barrier per step).
 #include "common.h"
 
 namespace {
@@ -18,10 +18,17 @@ namespace {
 constexpr int TN_BN = 128;            // output rows (columns of a) per workgroup
 constexpr int TN_BK = 128;            // output columns (columns of b) per workgroup
 constexpr int TN_BM = 64;             // reduction rows per step
-constexpr int TN_RS = TN_BN * 2 + 16; // LDS row stride in bytes
+// LDS row stride in bytes: 256 + 64, so the four rows a transposing read touches per half-wave (4 x 64 bytes) fall
+// in four different quarters of the 64 banks
+constexpr int TN_RS = TN_BN * 2 + 64;
 constexpr int TN_TILE = TN_BM * TN_RS;
 constexpr int TN_TARGET_WGS = 768;    // workgroups wanted in flight (256 CUs x 2 resident + slack)
 constexpr int TN_MIN_ROWS = 512;      // reduction rows a slice should at least own
+
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+struct TnStage {   // one thread's share of a 64-row step of both operands
+  u32x4_t a[4], b[4];
+};
 
 __device__ __forceinline__ u16x4_t tn_tr_read(const char* lds_addr) {
   s16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(lds_addr));
@@ -40,40 +47,53 @@ __device__ __forceinline__ bf16x8_t tn_frag(const char* a0) {
 __global__ __launch_bounds__(256) void gemm_tn_kernel(const bf16_t* __restrict__ a, int64_t lda,
                                                       const bf16_t* __restrict__ b, int64_t ldb,
                                                       float* __restrict__ dst, int64_t ldd, int64_t slice_stride, int M,
-                                                      int N, int K, int rows_per_slice, int tiles_k) {
+                                                      int N, int K, int rows_per_slice, int tiles_k, int nslices) {
   extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 buffers][a tile, b tile]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, hh = lane >> 5;
-  const int tn = blockIdx.x / tiles_k, tk = blockIdx.x - tn * tiles_k;
+  // Workgroups are dealt to the 8 XCDs round-robin by their linear index.  The slice is the fast index, so (with a
+  // slice count that is a multiple of 8) all tiles of one slice run on one XCD and share its L2: each 64-row step of
+  // the slice's rows is fetched from HBM once per XCD instead of once per output tile.
+  const int slice = blockIdx.x % nslices, tile = blockIdx.x / nslices;
+  const int tn = tile / tiles_k, tk = tile - tn * tiles_k;
   const int n0 = tn * TN_BN, k0 = tk * TN_BK;
-  const int m_begin = blockIdx.y * rows_per_slice;
+  const int m_begin = slice * rows_per_slice;
   int m_end = m_begin + rows_per_slice;
   m_end = m_end < M ? m_end : M;
   const int nsteps = (m_end - m_begin + TN_BM - 1) / TN_BM;
 
-  // staging: 1024 16-byte chunks per operand tile, four per thread
+  // staging: 1024 16-byte chunks per operand tile, four per thread, fetched with raw buffer loads whose descriptor
+  // ends at the slice's last row: rows past the slice (and the chunks of threads whose columns lie past N / K, which
+  // are given an offset beyond any descriptor) come back as zeros from the range check, with no branch, no clamp and
+  // no 64-bit address arithmetic in the loop.
   const int srow = tid >> 4, sch = tid & 15;            // + 16 rows per j
-  const bool a_ok = n0 + sch * 8 < N, b_ok = k0 + sch * 8 < K;
-  const bf16_t* ap = a + (int64_t)(m_begin + srow) * lda + n0 + sch * 8;
-  const bf16_t* bp = b + (int64_t)(m_begin + srow) * ldb + k0 + sch * 8;
+  const int rows_here = m_end > m_begin ? m_end - m_begin : 0;
+  const __amdgpu_buffer_rsrc_t ra_desc = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(a + (int64_t)m_begin * lda), 0, (int)((int64_t)rows_here * lda * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rb_desc = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(b + (int64_t)m_begin * ldb), 0, (int)((int64_t)rows_here * ldb * 2), 0x00020000);
+  const unsigned OOB = 0x80000000u;
+  unsigned va = n0 + sch * 8 < N ? (unsigned)((srow * lda + n0 + sch * 8) * 2) : OOB;
+  unsigned vb = k0 + sch * 8 < K ? (unsigned)((srow * ldb + k0 + sch * 8) * 2) : OOB;
+  const unsigned ja = (unsigned)(16 * lda * 2), jb = (unsigned)(16 * ldb * 2);   // 16 rows further
   const int soff = srow * TN_RS + sch * 16;
-  uint4 ra[4], rb[4];
-  auto fetch = [&](int step) {
-    const int mrow = m_begin + step * TN_BM + srow;
+  auto fetch = [&]() {   // the next 64 rows; advances the offsets
+    TnStage st;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const bool in = mrow + 16 * j < m_end;
-      const int64_t ro = (int64_t)(step * TN_BM + 16 * j);
-      ra[j] = (in && a_ok) ? *(const uint4*)(ap + ro * lda) : make_uint4(0, 0, 0, 0);
-      rb[j] = (in && b_ok) ? *(const uint4*)(bp + ro * ldb) : make_uint4(0, 0, 0, 0);
+      st.a[j] = __builtin_amdgcn_raw_buffer_load_b128(ra_desc, va, 0, 0);
+      st.b[j] = __builtin_amdgcn_raw_buffer_load_b128(rb_desc, vb, 0, 0);
+      va += ja;
+      vb += jb;
     }
+    return st;
   };
-  auto stash = [&](int buf) {
+  auto stash = [&](int buf, const TnStage st) {
     char* As = smem + buf * 2 * TN_TILE;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      *(uint4*)(As + soff + 16 * j * TN_RS) = ra[j];
-      *(uint4*)(As + TN_TILE + soff + 16 * j * TN_RS) = rb[j];
+      *(u32x4_t*)(As + soff + 16 * j * TN_RS) = st.a[j];
+      *(u32x4_t*)(As + TN_TILE + soff + 16 * j * TN_RS) = st.b[j];
     }
   };
 
@@ -89,16 +109,8 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const bf16_t* __restrict__
   const int tr_off = (4 * hh + (li >> 2)) * TN_RS + (16 * (g16 & 1) + 4 * (li & 3)) * 2;
   const int wn = wave >> 1, wk = wave & 1;
   const int a_off = tr_off + (64 * wn) * 2, b_off = TN_TILE + tr_off + (64 * wk) * 2;
-
-  if (nsteps > 0) {
-    fetch(0);
-    stash(0);
-  }
-  __syncthreads();
-  for (int step = 0; step < nsteps; ++step) {
-    const bool more = step + 1 < nsteps;
-    if (more) fetch(step + 1);
-    const char* base = smem + (step & 1) * 2 * TN_TILE;
+  auto compute = [&](int buf) {
+    const char* base = smem + buf * 2 * TN_TILE;
 #pragma unroll
     for (int s2 = 0; s2 < TN_BM / 16; ++s2) {
       const char* t = base + 16 * s2 * TN_RS;
@@ -109,11 +121,29 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const bf16_t* __restrict__
       acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
       acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
     }
-    if (more) stash((step + 1) & 1);
+  };
+
+  // registers hold the rows of the next two steps (R0: even steps, R1: odd steps) while LDS holds the current one
+  if (nsteps > 0) {   // block-uniform
+    TnStage r0 = fetch(), r1 = fetch();
+    stash(0, r0);
     __syncthreads();
+    int step = 0;
+    while (true) {
+      r0 = fetch();                     // step + 2
+      compute(0);
+      stash(1, r1);                     // step + 1 (zeros past the slice: written, never multiplied)
+      __syncthreads();
+      if (++step >= nsteps) break;
+      r1 = fetch();
+      compute(1);
+      stash(0, r0);
+      __syncthreads();
+      if (++step >= nsteps) break;
+    }
   }
 
-  float* out = dst + (int64_t)blockIdx.y * slice_stride;
+  float* out = dst + (int64_t)slice * slice_stride;
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -152,10 +182,11 @@ TnPlan tn_plan(int M, int N, int K) {
   const int64_t smax = (M + TN_MIN_ROWS - 1) / TN_MIN_ROWS;
   s = s > smax ? smax : s;
   s = s < 1 ? 1 : (s > 64 ? 64 : s);
+  if (s > 1 && smax >= 8) s = (s + 7) / 8 * 8;   // one or more whole slices per XCD
   int rps = (int)((M + s - 1) / s);
   rps = (rps + TN_BM - 1) / TN_BM * TN_BM;
   p.rows_per_slice = rps;
-  p.slices = (M + rps - 1) / rps;
+  p.slices = (int)s;                             // trailing slices may own no rows: they write zeros
   return p;
 }
 
@@ -175,22 +206,24 @@ extern "C" int vitm_gemm_tn(const void* a, int64_t lda, const void* b, int64_t l
                "vitm_gemm_tn: lda >= N, ldb >= K (both multiples of 8), ldo >= K");
   VITM_REQUIRE((((uintptr_t)a | (uintptr_t)b) & 15) == 0, "vitm_gemm_tn: operands must be 16-byte aligned");
   const TnPlan p = tn_plan(M, N, K);
-  VITM_REQUIRE((int64_t)p.tiles_n * p.tiles_k < (1ll << 31), "vitm_gemm_tn: grid too large for one launch");
+  VITM_REQUIRE((int64_t)p.tiles_n * p.tiles_k * p.slices < (1ll << 31), "vitm_gemm_tn: grid too large for one launch");
+  VITM_REQUIRE(((int64_t)p.rows_per_slice + 3 * TN_BM) * (lda > ldb ? lda : ldb) * 2 < (1ll << 31),
+               "vitm_gemm_tn: a slice of rows must stay below 2 GiB");
   const int64_t need = p.slices > 1 ? (int64_t)p.slices * N * K : 0;
   VITM_REQUIRE(need == 0 || (workspace && workspace_floats >= need),
                "vitm_gemm_tn: workspace of %lld floats needed (vitm_gemm_tn_workspace_floats)", (long long)need);
   hipStream_t st = (hipStream_t)stream;
   auto kfn = gemm_tn_kernel;
   VITM_LDS_OPTIN(kfn, 4 * TN_TILE, "vitm_gemm_tn");
-  const dim3 grid((unsigned)(p.tiles_n * p.tiles_k), (unsigned)p.slices);
+  const dim3 grid((unsigned)(p.tiles_n * p.tiles_k * p.slices));
   if (p.slices == 1) {
     hipLaunchKernelGGL(kfn, grid, dim3(256), 4 * TN_TILE, st, (const bf16_t*)a, lda, (const bf16_t*)b, ldb, out, ldo,
-                       (int64_t)0, M, N, K, p.rows_per_slice, p.tiles_k);
+                       (int64_t)0, M, N, K, p.rows_per_slice, p.tiles_k, p.slices);
     VITM_CHECK_LAUNCH("vitm_gemm_tn");
     return VITM_OK;
   }
   hipLaunchKernelGGL(kfn, grid, dim3(256), 4 * TN_TILE, st, (const bf16_t*)a, lda, (const bf16_t*)b, ldb, workspace,
-                     (int64_t)K, (int64_t)N * K, M, N, K, p.rows_per_slice, p.tiles_k);
+                     (int64_t)K, (int64_t)N * K, M, N, K, p.rows_per_slice, p.tiles_k, p.slices);
   VITM_CHECK_LAUNCH("vitm_gemm_tn");
   const int64_t total = (int64_t)N * K;
   int64_t g = (total + 255) / 256;

@@ -50,22 +50,22 @@ inline unsigned stream_grid(int64_t items, int per = 256, int cap = 4096) {
 }
 
 // ---- transpose: 32x32 tiles through LDS ------------------------------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(256) void transpose_kernel(const T* __restrict__ src, int64_t lds_, T* __restrict__ dst,
+template <typename TS, typename TD>
+__global__ __launch_bounds__(256) void transpose_kernel(const TS* __restrict__ src, int64_t lds_, TD* __restrict__ dst,
                                                         int64_t ldd, int M, int N, int Mpad) {
-  __shared__ T tile[32][33];
+  __shared__ float tile[32][33];
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
   const int m0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int m = m0 + ty + 8 * i, n = n0 + tx;
-    tile[ty + 8 * i][tx] = (m < M && n < N) ? src[(int64_t)m * lds_ + n] : (T)0;
+    tile[ty + 8 * i][tx] = (m < M && n < N) ? ldv(src + (int64_t)m * lds_ + n) : 0.f;
   }
   __syncthreads();
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int n = n0 + ty + 8 * i, m = m0 + tx;
-    if (n < N && m < Mpad) dst[(int64_t)n * ldd + m] = tile[tx][ty + 8 * i];   // rows m >= M were loaded as zero
+    if (n < N && m < Mpad) stv(dst + (int64_t)n * ldd + m, tile[tx][ty + 8 * i]);   // rows m >= M were loaded as zero
   }
 }
 
@@ -500,15 +500,20 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
 
 }  // namespace
 
-extern "C" int vitm_transpose(const void* src, int64_t lds, void* dst, int64_t ldd, int dtype, int M, int N, int m_pad,
-                              vitm_stream_t stream) {
+extern "C" int vitm_transpose(const void* src, int src_dtype, int64_t lds, void* dst, int dst_dtype, int64_t ldd, int M, int N,
+                              int m_pad, vitm_stream_t stream) {
   VITM_REQUIRE(src && dst, "vitm_transpose: null pointer");
-  VITM_REQUIRE(dtype == VITM_BF16 || dtype == VITM_F32, "vitm_transpose: bad dtype %d", dtype);
+  VITM_REQUIRE((src_dtype == VITM_BF16 || src_dtype == VITM_F32) && (dst_dtype == VITM_BF16 || dst_dtype == VITM_F32),
+               "vitm_transpose: bad dtype %d -> %d", src_dtype, dst_dtype);
   VITM_REQUIRE(M > 0 && N > 0 && lds >= N && m_pad >= M && ldd >= m_pad, "vitm_transpose: bad shape");
   dim3 grid((unsigned)((m_pad + 31) / 32), (unsigned)((N + 31) / 32));
   VITM_REQUIRE(grid.y < 65536, "vitm_transpose: N too large");
-  if (dtype == VITM_F32) hipLaunchKernelGGL(transpose_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)src, lds, (float*)dst, ldd, M, N, m_pad);
-  else hipLaunchKernelGGL(transpose_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, lds, (bf16_t*)dst, ldd, M, N, m_pad);
+  hipStream_t st = (hipStream_t)stream;
+  const bool sf = src_dtype == VITM_F32, df = dst_dtype == VITM_F32;
+  if (sf && df) hipLaunchKernelGGL((transpose_kernel<float, float>), grid, dim3(256), 0, st, (const float*)src, lds, (float*)dst, ldd, M, N, m_pad);
+  else if (sf) hipLaunchKernelGGL((transpose_kernel<float, bf16_t>), grid, dim3(256), 0, st, (const float*)src, lds, (bf16_t*)dst, ldd, M, N, m_pad);
+  else if (df) hipLaunchKernelGGL((transpose_kernel<bf16_t, float>), grid, dim3(256), 0, st, (const bf16_t*)src, lds, (float*)dst, ldd, M, N, m_pad);
+  else hipLaunchKernelGGL((transpose_kernel<bf16_t, bf16_t>), grid, dim3(256), 0, st, (const bf16_t*)src, lds, (bf16_t*)dst, ldd, M, N, m_pad);
   VITM_CHECK_LAUNCH("vitm_transpose");
   return VITM_OK;
 }

@@ -98,11 +98,13 @@ def pack_linear(weight: torch.Tensor, bias: Optional[torch.Tensor] = None,
     N, K = w.shape
     npad, kpad = round_up(N, 8), round_up(K, k_multiple())
     dev = w.device
-    wp = torch.zeros((npad, kpad), dtype=dtype, device=dev)
+    # the kernel writes rows 0 .. N-1 in full (K padding included); only the N padding needs clearing
     fold_ln = ln_weight is not None
-    s = torch.zeros(npad, dtype=torch.float32, device=dev) if fold_ln else None
-    c = torch.zeros(npad, dtype=torch.float32, device=dev)
-    g = torch.zeros(npad, dtype=torch.float32, device=dev) if out_scale is not None else None
+    alloc = torch.empty if npad == N else torch.zeros
+    wp = alloc((npad, kpad), dtype=dtype, device=dev)
+    s = alloc(npad, dtype=torch.float32, device=dev) if fold_ln else None
+    c = alloc(npad, dtype=torch.float32, device=dev)
+    g = alloc(npad, dtype=torch.float32, device=dev) if out_scale is not None else None
     b32, lw32, lb32, os32 = f32vec(bias), f32vec(ln_weight), f32vec(ln_bias), f32vec(out_scale)
     if fold_ln and lb32 is None:
         lb32 = torch.zeros_like(lw32)

@@ -9,7 +9,7 @@ from typing import Optional
 import torch
 
 from . import _lib
-from ._ops import _p, _dt, _stream, round_up, k_multiple, pack_linear, gemm, to_f32, to_bf16, EPI_BIAS
+from ._ops import _p, _dt, _stream, round_up, k_multiple, pack_linear, gemm, to_f32, to_bf16, EPI_BIAS, PackedLinear
 
 COLSUM_CHUNKS = 64
 LN_BWD_BLOCKS = 1024
@@ -57,13 +57,30 @@ def _delta(ref, B, H, N):
     return torch.empty(B * H * N, dtype=F32, device=ref.device)
 
 
-def transpose(src: torch.Tensor, M: int, N: int, m_pad: Optional[int] = None) -> torch.Tensor:
-    """[M, N] (row stride src.stride(0)) -> new [N, m_pad] of the same dtype with the pad columns zero."""
+def transpose(src: torch.Tensor, M: int, N: int, m_pad: Optional[int] = None, out_dtype: Optional[torch.dtype] = None,
+              rows: Optional[int] = None) -> torch.Tensor:
+    """[M, N] (row stride src.stride(0)) -> new [rows or N, m_pad] in out_dtype (default: the source's) with the pad
+    columns (and pad rows) zero."""
     m_pad = M if m_pad is None else m_pad
-    dst = torch.empty((N, m_pad), dtype=src.dtype, device=src.device)
-    _lib.check(_lib.load().vitm_transpose(_p(src), src.stride(0), _p(dst), m_pad, _rm(src), M, N, m_pad, _stream()),
+    rows = N if rows is None else rows
+    dt = src.dtype if out_dtype is None else out_dtype
+    dst = (torch.empty if rows == N else torch.zeros)((rows, m_pad), dtype=dt, device=src.device)
+    assert src.stride(-1) == 1
+    _lib.check(_lib.load().vitm_transpose(_p(src), _dt(src), src.stride(0), _p(dst), _dt(dst), m_pad, M, N, m_pad, _stream()),
                "vitm_transpose")
     return dst
+
+
+_ZEROS = {}
+
+
+def _zeros_f32(device, n: int) -> torch.Tensor:
+    """A shared all-zero fp32 vector (the bias of a GEMM that has none); never written."""
+    key = (device, n)
+    z = _ZEROS.get(key)
+    if z is None:
+        z = _ZEROS[key] = torch.zeros(n, dtype=F32, device=device)
+    return z
 
 
 def colsum(a: torch.Tensor, M: int, D: int, b: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -140,8 +157,10 @@ def linear_dx(dy: torch.Tensor, weight: torch.Tensor, M: int, out: Optional[torc
     """dx[M, K] = dy[M, N] . W[N, K]  (nn.Linear weight layout): the forward GEMM with W^T as the packed operand.
     dy's dtype is the compute dtype (the fp32 master weight is packed to it); dx comes back in it."""
     N, K = weight.shape
-    wt = transpose(weight.detach().contiguous(), N, K)              # [K, N], the weight's own dtype
-    pk = pack_linear(wt, None, dtype=dy.dtype)                      # rows K (padded to 8), cols N (padded to 64)
+    # W^T in the compute dtype, K of the GEMM (= N) padded to its multiple, rows (= K) padded to 8: one kernel
+    kpad, npad = round_up(N, k_multiple()), round_up(K, 8)
+    wt = transpose(weight.detach().contiguous(), N, K, kpad, out_dtype=dy.dtype, rows=npad)
+    pk = PackedLinear(wt, None, _zeros_f32(dy.device, npad), None, K, N, npad, kpad)
     dyp = dy
     if dy.shape[1] < pk.kpad:                                       # pad dy's columns to the GEMM's K multiple
         dyp = torch.zeros((M, pk.kpad), dtype=dy.dtype, device=dy.device)
@@ -169,15 +188,22 @@ def gemm_tn(a: torch.Tensor, b: torch.Tensor, M: int, N: int, K: int, out: Optio
     return out
 
 
-def linear_dw(dy: torch.Tensor, x: torch.Tensor, M: int, N: int, K: int) -> torch.Tensor:
-    """dW[N, K] (fp32) = dy[:, :N]^T . x[:, :K]: the forward GEMM on the two transposed activations (rows padded to
-    its K multiple); bf16 operands accumulate and store in fp32."""
+def linear_dw(dy: torch.Tensor, x: torch.Tensor, M: int, N: int, K: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """dW[N, K] (fp32) = dy[:, :N]^T . x[:, :K].  bf16 operands: the transposing weight-gradient GEMM, fp32 accumulators
+    stored as fp32.  fp32 operands: the forward GEMM on the two transposed activations (rows padded to its K multiple).
+    ``out`` (contiguous [N, K] fp32) receives the result when given."""
     if dy.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and _tn_ok(dy) and _tn_ok(x):
-        return gemm_tn(dy, x, M, N, K)
+        return gemm_tn(dy, x, M, N, K, out)
     mp = round_up(M, k_multiple())
     dyt = transpose(dy, M, N, mp)                                   # [N, mp]
     xt = transpose(x, M, K, mp)                                     # [K, mp]
     pk = pack_linear(xt, None, dtype=dy.dtype)                      # "weight" = x^T: rows K, cols mp
-    out = torch.empty((N, pk.npad), dtype=F32, device=dy.device)
-    gemm(dyt, pk, out, EPI_BIAS, N)
-    return out[:, :K]
+    if out is not None and pk.npad == K:
+        gemm(dyt, pk, out, EPI_BIAS, N)
+        return out
+    res = torch.empty((N, pk.npad), dtype=F32, device=dy.device)
+    gemm(dyt, pk, res, EPI_BIAS, N)
+    if out is not None:
+        out.copy_(res[:, :K])
+        return out
+    return res[:, :K]

@@ -174,16 +174,31 @@ def forward_train(model, img: torch.Tensor, compute_dtype: Optional[torch.dtype]
 # ----------------------------------------------------------------------------------------------------------------
 # backward
 # ----------------------------------------------------------------------------------------------------------------
-def _linear_backward(G: Dict, lin: nn.Linear, dy: torch.Tensor, x_in: torch.Tensor, M: int, need_dx: bool = True):
+class _Grads(dict):
+    """parameter -> gradient tensor.  With a ``sink`` (parameter -> preallocated fp32 tensor of the parameter's shape,
+    e.g. the views of a flat gradient buffer) the kernels write the gradients straight into it."""
+
+    def __init__(self, sink=None):
+        super().__init__()
+        self.sink = sink
+
+    def buf(self, p: torch.Tensor, *shape) -> torch.Tensor:
+        """The (uninitialised) gradient tensor of p, viewed as ``shape`` (default: flat)."""
+        t = self.sink[p] if self.sink is not None else torch.empty(p.shape, dtype=F32, device=p.device)
+        self[p] = t
+        return t.view(*shape) if shape else t.view(-1)
+
+
+def _linear_backward(G: _Grads, lin: nn.Linear, dy: torch.Tensor, x_in: torch.Tensor, M: int, need_dx: bool = True):
     """Gradients of y = x W^T + b: G[weight], G[bias]; returns dx [M, >= in_features] (or None)."""
     N, K = lin.weight.shape
-    G[lin.weight] = T.linear_dw(dy, x_in, M, N, K)
+    T.linear_dw(dy, x_in, M, N, K, out=G.buf(lin.weight, N, K))
     if lin.bias is not None:
-        G[lin.bias] = T.colsum(dy, M, N)
+        T.colsum(dy, M, N, out=G.buf(lin.bias))
     return T.linear_dx(dy, lin.weight, M) if need_dx else None
 
 
-def _block_backward(G: Dict, blk: Block, s: dict, dx2: torch.Tensor, B: int, N: int) -> torch.Tensor:
+def _block_backward(G: _Grads, blk: Block, s: dict, dx2: torch.Tensor, B: int, N: int) -> torch.Tensor:
     D, M, dev, cd = blk.dim, B * N, dx2.device, dx2.dtype
     attn, mlp = blk.attn, blk.mlp
     H, hd, hid = attn.num_heads, attn.head_dim, mlp.hidden_features
@@ -191,7 +206,7 @@ def _block_backward(G: Dict, blk: Block, s: dict, dx2: torch.Tensor, B: int, N: 
     g1, g2 = _ops.f32vec(blk.ls1.gamma), _ops.f32vec(blk.ls2.gamma)
 
     # ---- MLP branch: x2 = x1 + g2 * z2, z2 = fc2(gelu(pre)), pre = fc1(LN2(x1))
-    G[blk.ls2.gamma] = T.colsum(dx2, M, D, s["z2"])
+    T.colsum(dx2, M, D, s["z2"], out=G.buf(blk.ls2.gamma))
     dz2 = torch.empty((M, _ops.round_up(D, 8)), dtype=cd, device=dev)
     _ops.scale_channels(dx2[:, :dz2.shape[1]] if dx2.shape[1] != dz2.shape[1] else dx2, dz2, M, _ops.round_up(D, 8), _pad8(g2))
     dh = _linear_backward(G, mlp.linear_layer2, dz2, s["h"], M)
@@ -204,14 +219,12 @@ def _block_backward(G: Dict, blk: Block, s: dict, dx2: torch.Tensor, B: int, N: 
     dn2 = _linear_backward(G, mlp.linear_layer1, dpre, n2, M)
     dx1 = _buf(M, D, dev, cd)
     if ln2 is not None:
-        G[ln2[3]] = torch.empty(D, dtype=F32, device=dev)
-        G[ln2[4]] = torch.empty(D, dtype=F32, device=dev)
-        T.layernorm_bwd(s["x1"], dn2, ln2[0], ln2[2], M, D, dx1, dx_add=dx2, dw_out=G[ln2[3]], db_out=G[ln2[4]])
+        T.layernorm_bwd(s["x1"], dn2, ln2[0], ln2[2], M, D, dx1, dx_add=dx2, dw_out=G.buf(ln2[3]), db_out=G.buf(ln2[4]))
     else:
         _add(dx2, dn2, dx1, M, D)
 
     # ---- attention branch: x1 = x + g1 * z1, z1 = proj(attn(qkv)), qkv = Wqkv LN1(x)
-    G[blk.ls1.gamma] = T.colsum(dx1, M, D, s["z1"])
+    T.colsum(dx1, M, D, s["z1"], out=G.buf(blk.ls1.gamma))
     dz1 = dz2
     _ops.scale_channels(dx1[:, :dz1.shape[1]] if dx1.shape[1] != dz1.shape[1] else dx1, dz1, M, _ops.round_up(D, 8), _pad8(g1))
     d_o = _linear_backward(G, attn.proj, dz1, s["o"], M)
@@ -224,9 +237,7 @@ def _block_backward(G: Dict, blk: Block, s: dict, dx2: torch.Tensor, B: int, N: 
     dn1 = _linear_backward(G, attn.qkv, dqkv, n1, M)
     dx = _buf(M, D, dev, cd)
     if ln1 is not None:
-        G[ln1[3]] = torch.empty(D, dtype=F32, device=dev)
-        G[ln1[4]] = torch.empty(D, dtype=F32, device=dev)
-        T.layernorm_bwd(s["x"], dn1, ln1[0], ln1[2], M, D, dx, dx_add=dx1, dw_out=G[ln1[3]], db_out=G[ln1[4]])
+        T.layernorm_bwd(s["x"], dn1, ln1[0], ln1[2], M, D, dx, dx_add=dx1, dw_out=G.buf(ln1[3]), db_out=G.buf(ln1[4]))
     else:
         _add(dx1, dn1, dx, M, D)
     return dx
@@ -250,13 +261,14 @@ def _add(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, M: int, D: int) ->
     T.residual_scale(a, b, ones, out, M, D)
 
 
-def backward_train(model, S: dict, dlogits: torch.Tensor) -> Dict[nn.Parameter, torch.Tensor]:
-    """Gradients of every parameter given d(loss)/d(logits) [B, C]."""
+def backward_train(model, S: dict, dlogits: torch.Tensor, sink=None) -> Dict[nn.Parameter, torch.Tensor]:
+    """Gradients of every parameter given d(loss)/d(logits) [B, C]; written into ``sink`` (parameter -> fp32 tensor)
+    when one is given, into fresh tensors otherwise."""
     vt: VisionTransformer = model.vit_model
     pe: PatchEmbed = vt.patch_embed
     B, N, M, D, has_cls, cd = S["B"], S["N"], S["M"], S["D"], S["has_cls"], S["cd"]
     dev = dlogits.device
-    G: Dict[nn.Parameter, torch.Tensor] = {}
+    G = _Grads(sink)
     dl = dlogits.contiguous()
     if cd != F32:
         dl = _ops.to_bf16(dl)
@@ -269,9 +281,7 @@ def backward_train(model, S: dict, dlogits: torch.Tensor) -> Dict[nn.Parameter, 
     dxc = dx.view(B, N, ld)[:, 0]                          # gradient lands in the class-token rows
     fin = _ln(vt.norm_final, "VisionTransformer.norm_final")
     if fin is not None:
-        G[fin[3]] = torch.empty(D, dtype=F32, device=dev)
-        G[fin[4]] = torch.empty(D, dtype=F32, device=dev)
-        T.layernorm_bwd(xL.view(B, N, ld)[:, 0], dnf, fin[0], fin[2], B, D, dxc, dw_out=G[fin[3]], db_out=G[fin[4]])
+        T.layernorm_bwd(xL.view(B, N, ld)[:, 0], dnf, fin[0], fin[2], B, D, dxc, dw_out=G.buf(fin[3]), db_out=G.buf(fin[4]))
     else:
         dxc.copy_(dnf[:, :ld] if dnf.shape[1] >= ld else torch.nn.functional.pad(dnf, (0, ld - dnf.shape[1])))
 
@@ -281,31 +291,27 @@ def backward_train(model, S: dict, dlogits: torch.Tensor) -> Dict[nn.Parameter, 
 
     # ---- x0 = LN_pre(xcat) + pos ; xcat = [cls ; LN_e(tok)] ; tok = im2col(img) Wpe^T (+ b)
     dpos = T.colsum(dx.view(B, N * ld), B, N * ld)         # sum over the batch
-    G[vt.pos_embed] = dpos.view(N, ld)[:, :D].reshape(1, N, D)
+    G.buf(vt.pos_embed, N, D).copy_(dpos.view(N, ld)[:, :D])
     npre = _ln(vt.norm_pre, "VisionTransformer.norm_pre")
     dxcat = dx
     if npre is not None:
         dxcat = _buf(M, D, dev, cd)
-        G[npre[3]] = torch.empty(D, dtype=F32, device=dev)
-        G[npre[4]] = torch.empty(D, dtype=F32, device=dev)
-        T.layernorm_bwd(S["xcat"], dx, npre[0], npre[2], M, D, dxcat, dw_out=G[npre[3]], db_out=G[npre[4]])
+        T.layernorm_bwd(S["xcat"], dx, npre[0], npre[2], M, D, dxcat, dw_out=G.buf(npre[3]), db_out=G.buf(npre[4]))
     if has_cls:
-        G[vt.class_token] = T.colsum(dxcat.view(B, N * ld), B, D).reshape(1, 1, D)
+        T.colsum(dxcat.view(B, N * ld), B, D, out=G.buf(vt.class_token))
         dxcat.view(B, N, ld)[:, 0].zero_()                 # the class-token rows carry no patch gradient
     en = _ln(pe.norm_layer, "PatchEmbed.norm_layer")
     dtok = dxcat
     if en is not None:
         dtok = _buf(M, D, dev, cd)
-        G[en[3]] = torch.empty(D, dtype=F32, device=dev)
-        G[en[4]] = torch.empty(D, dtype=F32, device=dev)
-        T.layernorm_bwd(S["tok"], dxcat, en[0], en[2], M, D, dtok, dw_out=G[en[3]], db_out=G[en[4]])
+        T.layernorm_bwd(S["tok"], dxcat, en[0], en[2], M, D, dtok, dw_out=G.buf(en[3]), db_out=G.buf(en[4]))
         if has_cls:
             dtok.view(B, N, ld)[:, 0].zero_()
     Wpe = pe.projection.weight
     Dp, Kp = Wpe.shape[0], Wpe[0].numel()
-    G[Wpe] = T.linear_dw(dtok, S["A"], M, Dp, Kp).reshape(Wpe.shape)
+    T.linear_dw(dtok, S["A"], M, Dp, Kp, out=G.buf(Wpe, Dp, Kp))
     if pe.projection.bias is not None:
-        G[pe.projection.bias] = T.colsum(dtok, M, Dp)
+        T.colsum(dtok, M, Dp, out=G.buf(pe.projection.bias))
     return G
 
 
@@ -328,18 +334,25 @@ class _VitcFunction(torch.autograd.Function):
         return (None, None, None) + tuple(G.get(p).reshape(p.shape) if G.get(p) is not None else None for p in ctx.params)
 
 
-def vitc_forward_with_grad(model, img: torch.Tensor, compute_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
-    """``model(img)`` with an autograd graph: fp32 logits whose ``backward`` fills every parameter's ``.grad``.
-    ``compute_dtype`` (default: the images' dtype) picks fp32 or bf16 mixed precision; parameters are fp32 in both."""
+def _check_trainable(model, img: torch.Tensor, compute_dtype: Optional[torch.dtype]):
+    """(compute dtype, parameter list) or an exception that says why this model / input cannot take the training path."""
     why = supported(model)
     if why is not None:
         raise NotImplementedError(f"training path: {why}")
+    _ops.require_cuda(img, "training step")
     cd = _ops.compute_dtype(img) if compute_dtype is None else compute_dtype
     if cd not in (F32, torch.bfloat16):
         raise TypeError(f"compute_dtype {cd} unsupported (torch.float32 or torch.bfloat16)")
     params = [p for p in model.parameters()]
     if any(p.dtype != F32 for p in params):
         raise TypeError("the training path needs fp32 (master) parameters, also for bf16 compute")
+    return cd, params
+
+
+def vitc_forward_with_grad(model, img: torch.Tensor, compute_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+    """``model(img)`` with an autograd graph: fp32 logits whose ``backward`` fills every parameter's ``.grad``.
+    ``compute_dtype`` (default: the images' dtype) picks fp32 or bf16 mixed precision; parameters are fp32 in both."""
+    cd, params = _check_trainable(model, img, compute_dtype)
     return _VitcFunction.apply(model, img, cd, *params)
 
 
@@ -379,10 +392,17 @@ class FlatGradients:
         total = sum(p.numel() for p in self.params)
         dev = self.params[0].device
         self.flat = torch.zeros(total, dtype=F32, device=dev)
+        self.views = {}
         off = 0
         for p in self.params:
-            p.grad = self.flat[off:off + p.numel()].view(p.shape)
+            p.grad = self.views[p] = self.flat[off:off + p.numel()].view(p.shape)
             off += p.numel()
+
+    def attach(self) -> None:
+        """Make every ``.grad`` the view into the flat buffer again (``zero_grad(set_to_none=True)`` drops them)."""
+        for p in self.params:
+            if p.grad is not self.views[p]:
+                p.grad = self.views[p]
 
     def zero(self) -> None:
         self.flat.zero_()
@@ -409,16 +429,98 @@ class FlatGradients:
             self.flat.div_(dist.get_world_size(group))
 
 
+class FlatParameters:
+    """Every parameter's storage moved (values kept) into one flat fp32 buffer, each ``p.data`` a view of it: one kernel
+    can then update the whole model.  ``load_state_dict`` and in-place edits keep the views; ``model.to()`` / ``.float()``
+    re-allocate the parameters and so detach them (the optimizer notices and falls back to one launch per tensor)."""
+
+    def __init__(self, params):
+        self.params = [p for p in params if p.requires_grad]
+        if any(p.dtype != F32 or not p.is_cuda for p in self.params):
+            raise TypeError("FlatParameters holds fp32 CUDA parameters")
+        total = sum(p.numel() for p in self.params)
+        self.flat = torch.empty(total, dtype=F32, device=self.params[0].device)
+        self.offsets = []
+        off = 0
+        with torch.no_grad():
+            for p in self.params:
+                v = self.flat[off:off + p.numel()].view(p.shape)
+                v.copy_(p.data)
+                p.data = v
+                self.offsets.append(off)
+                off += p.numel()
+
+    def intact(self) -> bool:
+        base = self.flat.data_ptr()
+        return all(p.data_ptr() == base + 4 * o for p, o in zip(self.params, self.offsets))
+
+
 class AdamW(torch.optim.Optimizer):
     """torch.optim.AdamW (train.py:68-72) with the update in a HIP kernel; state_dict layout is torch's, so optimizer
     states saved by the reference load and the torch LR schedulers drive it."""
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self._flat = None
+
+    # ---- one launch for the whole model when parameters and gradients each live in one flat buffer ---------------
+    def use_flat(self, params: "FlatParameters", grads: "FlatGradients") -> bool:
+        """Update all parameters with one kernel launch from now on.  Needs a single parameter group holding exactly
+        the tensors of ``params`` / ``grads`` in their order; returns False (and changes nothing) otherwise."""
+        if len(self.param_groups) != 1:
+            return False
+        ps = self.param_groups[0]["params"]
+        if len(ps) != len(params.params) or any(a is not b for a, b in zip(ps, params.params)) \
+                or len(ps) != len(grads.params) or any(a is not b for a, b in zip(ps, grads.params)):
+            return False
+        m, v = torch.zeros_like(params.flat), torch.zeros_like(params.flat)
+        self._flat = (params, grads, m, v)
+        self._seed_flat_state()
+        return True
+
+    def _seed_flat_state(self) -> None:
+        """Per-parameter state entries become views of the flat moment buffers (torch's state_dict layout is kept);
+        existing state (a loaded checkpoint) is copied in first.  All parameters share one step counter."""
+        params, _, m, v = self._flat
+        step = None
+        for p, off in zip(params.params, params.offsets):
+            st = self.state[p]
+            mv, vv = m[off:off + p.numel()].view(p.shape), v[off:off + p.numel()].view(p.shape)
+            if len(st) != 0:
+                mv.copy_(st["exp_avg"])
+                vv.copy_(st["exp_avg_sq"])
+                step = st["step"] if step is None else step
+            st["exp_avg"], st["exp_avg_sq"] = mv, vv
+        step = torch.tensor(0.0) if step is None else torch.as_tensor(float(step))
+        for p in params.params:
+            self.state[p]["step"] = step
+
+    def load_state_dict(self, state_dict) -> None:
+        super().load_state_dict(state_dict)
+        if self._flat is not None:
+            self._seed_flat_state()
+
+    def _flat_step(self) -> bool:
+        params, grads, m, v = self._flat
+        group = self.param_groups[0]
+        if not params.intact() or any(p.grad is None or p.grad.data_ptr() != grads.views[p].data_ptr() for p in params.params):
+            return False
+        step = self.state[params.params[0]]["step"]
+        step += 1
+        b1, b2 = group["betas"]
+        with torch.cuda.device(params.flat.device):
+            T.adamw(params.flat, grads.flat, m, v, group["lr"], b1, b2, group["eps"], group["weight_decay"], int(step.item()))
+        for p in params.params:
+            torch.autograd.graph.increment_version(p)       # cached packed weights must be rebuilt
+        return True
 
     @torch.no_grad()
     def step(self, closure=None):
         loss = closure() if closure is not None else None
+        if self._flat is not None:
+            if self._flat_step():
+                return loss
+            self._unflatten_state()
         for group in self.param_groups:
             b1, b2 = group["betas"]
             for p in group["params"]:
@@ -439,6 +541,20 @@ class AdamW(torch.optim.Optimizer):
         return loss
 
 
+def _unflatten_state(self) -> None:
+    """Leave flat mode for good: the state entries get storage of their own and a step counter each."""
+    params = self._flat[0]
+    self._flat = None
+    for p in params.params:
+        st = self.state[p]
+        if len(st) != 0:
+            st["exp_avg"], st["exp_avg_sq"] = st["exp_avg"].clone(), st["exp_avg_sq"].clone()
+            st["step"] = st["step"].clone()
+
+
+AdamW._unflatten_state = _unflatten_state
+
+
 def reference_optimizer_and_scheduler(model, total_iters: int):
     """The optimizer / scheduler of the reference's ``getOptimizerAndSchedular`` (train.py:65-93)."""
     opt = AdamW(model.parameters(), lr=1e-3, weight_decay=0.05, betas=(0.9, 0.98))
@@ -457,14 +573,27 @@ class Trainer:
         self.model, self.optimizer, self.scheduler, self.max_norm, self.group = model, optimizer, scheduler, max_norm, group
         self.compute_dtype = compute_dtype          # None: follow the images (fp32 images -> fp32, bf16 -> mixed precision)
         self.grads = FlatGradients(model.parameters())
+        self.params = None
+        if isinstance(optimizer, AdamW):             # one flat parameter buffer -> one AdamW launch per step
+            flat = FlatParameters(model.parameters())
+            if optimizer.use_flat(flat, self.grads):
+                self.params = flat
         self.criterion = CrossEntropyLoss()
         self.last_grad_norm = None
 
     def step(self, images: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
-        self.grads.zero()
-        logits = vitc_forward_with_grad(self.model, images, self.compute_dtype)
-        loss = self.criterion(logits, labels)
-        loss.backward()
+        """zero_grad, forward, loss, backward, all-reduce, clip, optimizer and scheduler step.  The backward kernels
+        write every gradient straight into the flat buffer (no autograd graph, no accumulation pass)."""
+        cd, _ = _check_trainable(self.model, images, self.compute_dtype)
+        with torch.no_grad(), torch.cuda.device(images.device):
+            self.grads.attach()
+            logits, S = forward_train(self.model, images, cd)
+            loss, dl = T.cross_entropy(logits, labels, want_grad=True)
+            G = backward_train(self.model, S, dl, sink=self.grads.views)
+            for p in self.grads.params:              # a parameter the backward did not reach keeps no stale gradient
+                if p not in G:
+                    self.grads.views[p].zero_()
+            loss = loss.reshape(())
         self.grads.all_reduce(self.group)
         self.last_grad_norm = self.grads.clip_grad_norm_(self.max_norm)
         self.optimizer.step()
