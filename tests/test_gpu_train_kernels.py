@@ -246,7 +246,9 @@ def test_gemm_tn(T, M, N, K):
     kr = (K + 7) // 8 * 8
     a[:, N:nr] = 0          # the 16-byte chunk that straddles the last column is read: it must hold numbers
     b[:, K:kr] = 0
-    out = T.gemm_tn(a, b, M, N, K)
+    cs = torch.full((N,), float("nan"), device=DEV)
+    out = T.gemm_tn(a, b, M, N, K, colsum_out=cs)
     ref = a[:, :N].double().t() @ b[:, :K].double()
     assert _rel(out, ref) <= 1e-5
+    assert _rel(cs, a[:, :N].double().sum(0)) <= 1e-5, "bias gradient from the same pass"
     assert torch.equal(out, T.gemm_tn(a, b, M, N, K)), "deterministic"

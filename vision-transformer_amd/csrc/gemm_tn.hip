@@ -9,8 +9,8 @@
 // The output is small (a weight matrix) and the reduction is long (every token of the batch), so the reduction is split
 // over workgroup slices: each slice writes its own fp32 partial tile and a second kernel adds the slices in a
 // fixed order (deterministic; no atomics).  Workgroup = 4 waves, 128 x 128 output tile, 64 x 64 per wave as 2 x 2
-// v_mfma_f32_32x32x16_bf16 tiles; the global loads of the next two 64-row steps are in flight while the current one is
-// multiplied (two register sets, two LDS buffers, one barrier per step).
+// v_mfma_f32_32x32x16_bf16 tiles; the global loads of the next 64-row step are in flight while the current one is
+// multiplied (register staging, two LDS buffers, one barrier per step).
 #include "common.h"
 
 namespace {
@@ -44,10 +44,11 @@ __device__ __forceinline__ bf16x8_t tn_frag(const char* a0) {
   return __builtin_bit_cast(bf16x8_t, t);
 }
 
-__global__ __launch_bounds__(256) void gemm_tn_kernel(const bf16_t* __restrict__ a, int64_t lda,
+__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const bf16_t* __restrict__ a, int64_t lda,
                                                       const bf16_t* __restrict__ b, int64_t ldb,
-                                                      float* __restrict__ dst, int64_t ldd, int64_t slice_stride, int M,
-                                                      int N, int K, int rows_per_slice, int tiles_k, int nslices) {
+                                                      float* __restrict__ dst, int64_t ldd, int64_t slice_stride,
+                                                      float* __restrict__ csum, int M, int N, int K, int rows_per_slice,
+                                                      int tiles_k, int nslices) {
   extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 buffers][a tile, b tile]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, hh = lane >> 5;
@@ -109,6 +110,18 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const bf16_t* __restrict__
   const int tr_off = (4 * hh + (li >> 2)) * TN_RS + (16 * (g16 & 1) + 4 * (li & 3)) * 2;
   const int wn = wave >> 1, wk = wave & 1;
   const int a_off = tr_off + (64 * wn) * 2, b_off = TN_TILE + tr_off + (64 * wk) * 2;
+  // column sums of a (the bias gradient) ride along on the workgroups of the first column tile: one more product
+  // per a fragment, against a fragment of ones -- every column of that accumulator is sum_m a[m, n]
+  const bool want_csum = csum != nullptr && tk == 0 && wk == 0;   // wave-uniform
+  f32x16_t cacc[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) cacc[i][e] = 0.f;
+  u16x8_t ones_u;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) ones_u[j] = 0x3F80;
+  const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, ones_u);
   auto compute = [&](int buf) {
     const char* base = smem + buf * 2 * TN_TILE;
 #pragma unroll
@@ -120,29 +133,36 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const bf16_t* __restrict__
       acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
       acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
       acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+      if (want_csum) {
+        cacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, ones, cacc[0], 0, 0, 0);
+        cacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, ones, cacc[1], 0, 0, 0);
+      }
     }
   };
 
   // registers hold the rows of the next two steps (R0: even steps, R1: odd steps) while LDS holds the current one
   if (nsteps > 0) {   // block-uniform
-    TnStage r0 = fetch(), r1 = fetch();
-    stash(0, r0);
+    TnStage nxt = fetch();
+    stash(0, nxt);
     __syncthreads();
-    int step = 0;
-    while (true) {
-      r0 = fetch();                     // step + 2
-      compute(0);
-      stash(1, r1);                     // step + 1 (zeros past the slice: written, never multiplied)
+    for (int step = 0; step < nsteps; ++step) {
+      nxt = fetch();                    // rows of step + 1, in flight while this step is multiplied
+      compute(step & 1);
+      stash((step + 1) & 1, nxt);       // zeros past the slice: written, never multiplied
       __syncthreads();
-      if (++step >= nsteps) break;
-      r1 = fetch();
-      compute(1);
-      stash(0, r0);
-      __syncthreads();
-      if (++step >= nsteps) break;
     }
   }
 
+  if (want_csum && r == 0) {   // one lane per row pair half: lane column 0 of both halves
+    float* co = csum + (int64_t)slice * N;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int n = n0 + 64 * wn + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * hh;
+        if (n < N) co[n] = cacc[i][e];
+      }
+  }
   float* out = dst + (int64_t)slice * slice_stride;
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -158,9 +178,10 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const bf16_t* __restrict__
     }
 }
 
-// out[n, k] = sum over slices, in slice order
+// out[n, k] = sum over slices, in slice order; the same for the column sums when there are any
 __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict__ part, int64_t slice_stride, int slices,
-                                                        float* __restrict__ out, int64_t ldo, int N, int K) {
+                                                        float* __restrict__ out, int64_t ldo, int N, int K,
+                                                        const float* __restrict__ cpart, float* __restrict__ cout) {
   const int64_t total = (int64_t)N * K;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     float s = part[i];
@@ -168,6 +189,12 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict_
     const int64_t n = i / K;
     out[n * ldo + (i - n * K)] = s;
   }
+  if (cout != nullptr)
+    for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < N; n += gridDim.x * blockDim.x) {
+      float s = cpart[n];
+      for (int sl = 1; sl < slices; ++sl) s += cpart[n + (int64_t)sl * N];
+      cout[n] = s;
+    }
 }
 
 struct TnPlan {
@@ -195,11 +222,12 @@ TnPlan tn_plan(int M, int N, int K) {
 extern "C" int64_t vitm_gemm_tn_workspace_floats(int M, int N, int K) {
   if (M <= 0 || N <= 0 || K <= 0) return 0;
   const TnPlan p = tn_plan(M, N, K);
-  return p.slices > 1 ? (int64_t)p.slices * N * K : 0;
+  return p.slices > 1 ? (int64_t)p.slices * ((int64_t)N * K + N) : 0;
 }
 
-extern "C" int vitm_gemm_tn(const void* a, int64_t lda, const void* b, int64_t ldb, float* out, int64_t ldo, int M, int N,
-                            int K, float* workspace, int64_t workspace_floats, vitm_stream_t stream) {
+extern "C" int vitm_gemm_tn(const void* a, int64_t lda, const void* b, int64_t ldb, float* out, int64_t ldo,
+                            float* colsum_out, int M, int N, int K, float* workspace, int64_t workspace_floats,
+                            vitm_stream_t stream) {
   VITM_REQUIRE(a && b && out, "vitm_gemm_tn: null pointer");
   VITM_REQUIRE(M > 0 && N > 0 && K > 0, "vitm_gemm_tn: M, N, K must be positive");
   VITM_REQUIRE(lda >= N && ldb >= K && ldo >= K && lda % 8 == 0 && ldb % 8 == 0,
@@ -209,7 +237,7 @@ extern "C" int vitm_gemm_tn(const void* a, int64_t lda, const void* b, int64_t l
   VITM_REQUIRE((int64_t)p.tiles_n * p.tiles_k * p.slices < (1ll << 31), "vitm_gemm_tn: grid too large for one launch");
   VITM_REQUIRE(((int64_t)p.rows_per_slice + 3 * TN_BM) * (lda > ldb ? lda : ldb) * 2 < (1ll << 31),
                "vitm_gemm_tn: a slice of rows must stay below 2 GiB");
-  const int64_t need = p.slices > 1 ? (int64_t)p.slices * N * K : 0;
+  const int64_t need = p.slices > 1 ? (int64_t)p.slices * ((int64_t)N * K + N) : 0;
   VITM_REQUIRE(need == 0 || (workspace && workspace_floats >= need),
                "vitm_gemm_tn: workspace of %lld floats needed (vitm_gemm_tn_workspace_floats)", (long long)need);
   hipStream_t st = (hipStream_t)stream;
@@ -218,18 +246,19 @@ extern "C" int vitm_gemm_tn(const void* a, int64_t lda, const void* b, int64_t l
   const dim3 grid((unsigned)(p.tiles_n * p.tiles_k * p.slices));
   if (p.slices == 1) {
     hipLaunchKernelGGL(kfn, grid, dim3(256), 4 * TN_TILE, st, (const bf16_t*)a, lda, (const bf16_t*)b, ldb, out, ldo,
-                       (int64_t)0, M, N, K, p.rows_per_slice, p.tiles_k, p.slices);
+                       (int64_t)0, colsum_out, M, N, K, p.rows_per_slice, p.tiles_k, p.slices);
     VITM_CHECK_LAUNCH("vitm_gemm_tn");
     return VITM_OK;
   }
   hipLaunchKernelGGL(kfn, grid, dim3(256), 4 * TN_TILE, st, (const bf16_t*)a, lda, (const bf16_t*)b, ldb, workspace,
-                     (int64_t)K, (int64_t)N * K, M, N, K, p.rows_per_slice, p.tiles_k, p.slices);
+                     (int64_t)K, (int64_t)N * K, colsum_out ? workspace + (int64_t)p.slices * N * K : nullptr, M, N, K,
+                     p.rows_per_slice, p.tiles_k, p.slices);
   VITM_CHECK_LAUNCH("vitm_gemm_tn");
   const int64_t total = (int64_t)N * K;
   int64_t g = (total + 255) / 256;
   g = g > 4096 ? 4096 : g;
   hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)g), dim3(256), 0, st, (const float*)workspace, (int64_t)N * K,
-                     p.slices, out, ldo, N, K);
+                     p.slices, out, ldo, N, K, (const float*)workspace + (int64_t)p.slices * N * K, colsum_out);
   VITM_CHECK_LAUNCH("vitm_gemm_tn");
   return VITM_OK;
 }

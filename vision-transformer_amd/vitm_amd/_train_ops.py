@@ -175,25 +175,31 @@ def _tn_ok(t: torch.Tensor) -> bool:
     return t.stride(1) == 1 and t.stride(0) % 8 == 0 and t.data_ptr() % 16 == 0
 
 
-def gemm_tn(a: torch.Tensor, b: torch.Tensor, M: int, N: int, K: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+def gemm_tn(a: torch.Tensor, b: torch.Tensor, M: int, N: int, K: int, out: Optional[torch.Tensor] = None,
+            colsum_out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out[N, K] (fp32) = a[:M, :N]^T . b[:M, :K] for bf16 row-major a, b: no transposed copies, reduction split over
-    workgroup slices and summed in a fixed order."""
+    workgroup slices and summed in a fixed order.  ``colsum_out`` (N floats) also receives the column sums of a."""
     lib = _lib.load()
     if out is None:
         out = torch.empty((N, K), dtype=F32, device=a.device)
+    assert out.stride(1) == 1 and (colsum_out is None or (colsum_out.is_contiguous() and colsum_out.numel() == N))
     nws = lib.vitm_gemm_tn_workspace_floats(M, N, K)
     ws = torch.empty(nws, dtype=F32, device=a.device) if nws else None
-    _lib.check(lib.vitm_gemm_tn(_p(a), a.stride(0), _p(b), b.stride(0), _p(out), out.stride(0), M, N, K, _p(ws), nws,
-                                _stream()), "vitm_gemm_tn")
+    _lib.check(lib.vitm_gemm_tn(_p(a), a.stride(0), _p(b), b.stride(0), _p(out), out.stride(0), _p(colsum_out), M, N, K,
+                                _p(ws), nws, _stream()), "vitm_gemm_tn")
     return out
 
 
-def linear_dw(dy: torch.Tensor, x: torch.Tensor, M: int, N: int, K: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """dW[N, K] (fp32) = dy[:, :N]^T . x[:, :K].  bf16 operands: the transposing weight-gradient GEMM, fp32 accumulators
-    stored as fp32.  fp32 operands: the forward GEMM on the two transposed activations (rows padded to its K multiple).
-    ``out`` (contiguous [N, K] fp32) receives the result when given."""
+def linear_dw(dy: torch.Tensor, x: torch.Tensor, M: int, N: int, K: int, out: Optional[torch.Tensor] = None,
+              bias_out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """dW[N, K] (fp32) = dy[:, :N]^T . x[:, :K], and the bias gradient sum_m dy[m, :N] into ``bias_out`` when given.
+    bf16 operands: the transposing weight-gradient GEMM (fp32 accumulators stored as fp32, the bias gradient from the
+    same pass).  fp32 operands: the forward GEMM on the two transposed activations (rows padded to its K multiple) and
+    a column-sum kernel.  ``out`` (contiguous [N, K] fp32) receives dW when given."""
     if dy.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and _tn_ok(dy) and _tn_ok(x):
-        return gemm_tn(dy, x, M, N, K, out)
+        return gemm_tn(dy, x, M, N, K, out, bias_out)
+    if bias_out is not None:
+        colsum(dy, M, N, out=bias_out)
     mp = round_up(M, k_multiple())
     dyt = transpose(dy, M, N, mp)                                   # [N, mp]
     xt = transpose(x, M, K, mp)                                     # [K, mp]

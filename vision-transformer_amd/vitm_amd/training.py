@@ -192,9 +192,7 @@ class _Grads(dict):
 def _linear_backward(G: _Grads, lin: nn.Linear, dy: torch.Tensor, x_in: torch.Tensor, M: int, need_dx: bool = True):
     """Gradients of y = x W^T + b: G[weight], G[bias]; returns dx [M, >= in_features] (or None)."""
     N, K = lin.weight.shape
-    T.linear_dw(dy, x_in, M, N, K, out=G.buf(lin.weight, N, K))
-    if lin.bias is not None:
-        T.colsum(dy, M, N, out=G.buf(lin.bias))
+    T.linear_dw(dy, x_in, M, N, K, out=G.buf(lin.weight, N, K), bias_out=G.buf(lin.bias) if lin.bias is not None else None)
     return T.linear_dx(dy, lin.weight, M) if need_dx else None
 
 
@@ -309,9 +307,8 @@ def backward_train(model, S: dict, dlogits: torch.Tensor, sink=None) -> Dict[nn.
             dtok.view(B, N, ld)[:, 0].zero_()
     Wpe = pe.projection.weight
     Dp, Kp = Wpe.shape[0], Wpe[0].numel()
-    T.linear_dw(dtok, S["A"], M, Dp, Kp, out=G.buf(Wpe, Dp, Kp))
-    if pe.projection.bias is not None:
-        T.colsum(dtok, M, Dp, out=G.buf(pe.projection.bias))
+    T.linear_dw(dtok, S["A"], M, Dp, Kp, out=G.buf(Wpe, Dp, Kp),
+                bias_out=G.buf(pe.projection.bias) if pe.projection.bias is not None else None)
     return G
 
 
