@@ -13,4 +13,7 @@ SHORT="python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline"
 timeout -s KILL 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $SHORT > $OUT/pmc_fetch.log 2>&1
 timeout -s KILL 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- $SHORT > $OUT/pmc_write.log 2>&1
 timeout -s KILL 200 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_LDS_BANK_CONFLICT SQ_WAIT_ANY GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_sq -- $SHORT > $OUT/pmc_sq.log 2>&1
+# training step (informational): kernel trace + stats only
+timeout -s KILL 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/train_bf16 -- python3 bench.py --mode train --dtype bf16 --batch 256 --steps 3 --warmup 1 > $OUT/train_bf16.log 2>&1
+timeout -s KILL 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/train_f32 -- python3 bench.py --mode train --dtype f32 --batch 64 --steps 3 --warmup 1 > $OUT/train_f32.log 2>&1
 find $OUT -name "*.csv" | head -20

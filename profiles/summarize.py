@@ -46,6 +46,18 @@ def main(rnd: str) -> None:
                 avg_ns[k] = float(r["AverageNs"])
                 w.writerow([k, r["Calls"], r["TotalDurationNs"], f"{float(r['AverageNs']):.0f}", r["Percentage"],
                             r["MinNs"], r["MaxNs"]])
+    # ---- kernel stats of the training step (bench.py --mode train), when collected
+    for tag, cmd in (("train_bf16", "--mode train --dtype bf16 --batch 256"), ("train_f32", "--mode train --dtype f32 --batch 64")):
+        tstats = glob.glob(os.path.join(src, tag, "**", "*kernel_stats.csv"), recursive=True)
+        if not tstats:
+            continue
+        with open(os.path.join(out, f"{rnd}_{tag}_kernel_stats.csv"), "w", newline="") as f:
+            f.write(f"# rocprofv3 --kernel-trace --stats -- python3 bench.py {cmd} --steps 3 --warmup 1 (MI355X, ViT-B/16)\n")
+            w = csv.writer(f)
+            w.writerow(["kernel", "calls", "total_ns", "avg_ns", "percent", "min_ns", "max_ns"])
+            for r in csv.DictReader(open(tstats[0])):
+                w.writerow([short(r["Name"]), r["Calls"], r["TotalDurationNs"], f"{float(r['AverageNs']):.0f}", r["Percentage"],
+                            r["MinNs"], r["MaxNs"]])
     # ---- counters
     agg = collections.defaultdict(list)
     for path in glob.glob(os.path.join(src, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
