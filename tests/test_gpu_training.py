@@ -183,3 +183,73 @@ def test_bf16_training_with_padding_tracks_float64(monkeypatch):
     for k, p in model.named_parameters():
         c = _cos(p.grad.cpu(), sd64[k].grad)
         assert c >= (0.99 if p.numel() >= 1000 else 0.95), f"{k}: {c:.4f}"
+
+
+# ---- flat parameters / single-launch AdamW -------------------------------------------------------------------------
+def _batch(cfg, batch, seed):
+    x = torch.from_numpy(W.make_input(cfg, batch, seed)).cuda()
+    y = torch.randint(0, cfg["num_classes"], (batch,), generator=torch.Generator().manual_seed(seed)).cuda()
+    return x, y
+
+
+def test_trainer_matches_autograd_loop_with_torch_adamw():
+    """Trainer.step (gradients written in place, one AdamW launch over the flat buffers) against the reference's own
+    loop body run through this package's autograd path with torch.nn.utils.clip_grad_norm_ and torch.optim.AdamW."""
+    from vitm_amd import training
+    cfg = W.CONFIGS["tiny2"]
+    a, b = _model(cfg, 5), _model(cfg, 5)
+    opt_a = training.AdamW(a.parameters(), lr=1e-3, weight_decay=0.05, betas=(0.9, 0.98))
+    tr = training.Trainer(a, opt_a, None, max_norm=1.0)
+    assert tr.params is not None and tr.params.intact(), "parameters live in one flat buffer"
+    opt_b = torch.optim.AdamW(b.parameters(), lr=1e-3, weight_decay=0.05, betas=(0.9, 0.98))
+    crit = training.CrossEntropyLoss()
+    for step in range(3):
+        x, y = _batch(cfg, 6, 100 + step)
+        la = tr.step(x, y)
+        opt_b.zero_grad()
+        lb = crit(b(x), y)
+        lb.backward()
+        nb = torch.nn.utils.clip_grad_norm_(b.parameters(), max_norm=1.0)
+        opt_b.step()
+        assert abs(la.item() - lb.item()) <= 1e-5 * abs(lb.item()), step
+        assert abs(tr.last_grad_norm.item() - nb.item()) <= 1e-4 * nb.item(), step
+    for (k, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):
+        assert (pa - pb).abs().max().item() <= 2e-6, k
+    sd = opt_a.state_dict()
+    assert len(sd["state"]) == len(list(a.parameters())) and float(sd["state"][0]["step"]) == 3
+
+
+def test_flat_adamw_state_reloads_and_detached_parameters_fall_back():
+    import copy
+    from vitm_amd import training
+    cfg = W.CONFIGS["tiny2"]
+    a = _model(cfg, 7)
+    opt_a = training.AdamW(a.parameters(), lr=1e-3, weight_decay=0.05, betas=(0.9, 0.98))
+    tr_a = training.Trainer(a, opt_a, None, max_norm=1.0, compute_dtype=torch.bfloat16)
+    for step in range(2):
+        tr_a.step(*_batch(cfg, 6, 200 + step))
+    model_sd = {k: v.clone() for k, v in a.state_dict().items()}
+    opt_sd = copy.deepcopy(opt_a.state_dict())
+    x3, y3 = _batch(cfg, 6, 202)
+    tr_a.step(x3, y3)
+    # resume in a fresh trainer: bit-identical third step
+    b = _model(cfg, 1)
+    b.load_state_dict(model_sd)
+    opt_b = training.AdamW(b.parameters(), lr=1e-3, weight_decay=0.05, betas=(0.9, 0.98))
+    tr_b = training.Trainer(b, opt_b, None, max_norm=1.0, compute_dtype=torch.bfloat16)
+    opt_b.load_state_dict(opt_sd)
+    tr_b.step(x3, y3)
+    for (k, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):
+        assert torch.equal(pa, pb), k
+    # parameters re-allocated behind the trainer's back: the optimizer notices and updates tensor by tensor
+    c = _model(cfg, 1)
+    c.load_state_dict(model_sd)
+    opt_c = training.AdamW(c.parameters(), lr=1e-3, weight_decay=0.05, betas=(0.9, 0.98))
+    tr_c = training.Trainer(c, opt_c, None, max_norm=1.0, compute_dtype=torch.bfloat16)
+    opt_c.load_state_dict(opt_sd)
+    for p in c.parameters():
+        p.data = p.data.clone()
+    tr_c.step(x3, y3)
+    assert opt_c._flat is None
+    for (k, pa), (_, pc) in zip(a.named_parameters(), c.named_parameters()):
+        assert torch.equal(pa, pc), k

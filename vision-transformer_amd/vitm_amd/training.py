@@ -511,6 +511,16 @@ class AdamW(torch.optim.Optimizer):
             torch.autograd.graph.increment_version(p)       # cached packed weights must be rebuilt
         return True
 
+    def _unflatten_state(self) -> None:
+        """Leave flat mode for good: the state entries get storage of their own and a step counter each."""
+        params = self._flat[0]
+        self._flat = None
+        for p in params.params:
+            st = self.state[p]
+            if len(st) != 0:
+                st["exp_avg"], st["exp_avg_sq"] = st["exp_avg"].clone(), st["exp_avg_sq"].clone()
+                st["step"] = st["step"].clone()
+
     @torch.no_grad()
     def step(self, closure=None):
         loss = closure() if closure is not None else None
@@ -536,20 +546,6 @@ class AdamW(torch.optim.Optimizer):
                             group["weight_decay"], int(st["step"].item()))
                 torch.autograd.graph.increment_version(p)   # the kernel wrote p: cached packed weights must be rebuilt
         return loss
-
-
-def _unflatten_state(self) -> None:
-    """Leave flat mode for good: the state entries get storage of their own and a step counter each."""
-    params = self._flat[0]
-    self._flat = None
-    for p in params.params:
-        st = self.state[p]
-        if len(st) != 0:
-            st["exp_avg"], st["exp_avg_sq"] = st["exp_avg"].clone(), st["exp_avg_sq"].clone()
-            st["step"] = st["step"].clone()
-
-
-AdamW._unflatten_state = _unflatten_state
 
 
 def reference_optimizer_and_scheduler(model, total_iters: int):
