@@ -272,6 +272,16 @@ int vitm_layernorm_bwd(const void* x, int64_t ldx, const void* dy, int64_t lddy,
 int vitm_residual_scale(const void* resid, int64_t ldr, const void* z, int64_t ldz, const float* gamma, void* out,
                         int64_t ldo, int dtype, int M, int D, vitm_stream_t stream);
 
+/*
+ * Backward of the per-head LayerNorm of q and k (models.py:54-55,82; parallel_block.py:86).  qkv holds the values
+ * BEFORE the norm; dqkv holds d(loss)/d(normalised q, k) on entry and d(loss)/d(q, k) on return (the v third is left
+ * alone).  partial is [4][nblocks][head_dim] fp32: per-workgroup sums of (dq_w, dq_b, dk_w, dk_b), to be reduced over
+ * nblocks with vitm_colsum.
+ */
+int vitm_qk_norm_bwd(const void* qkv, int64_t ldqkv, void* dqkv, int64_t lddqkv, int dtype, int M, int H, int head_dim,
+                     const float* q_w, float q_eps, const float* k_w, float k_eps, float* partial, int nblocks,
+                     vitm_stream_t stream);
+
 /* dpre = dh * d/dx gelu_erf(pre): backward of nn.GELU() (models.py:128). */
 int vitm_gelu_bwd(const void* pre, int64_t ldp, const void* dh, int64_t ldh, void* dpre, int64_t ldd, int dtype, int M,
                   int D, vitm_stream_t stream);

@@ -76,11 +76,10 @@ def _allreduce_worker(rank, world, port, q):
         torch.manual_seed(0)
         lin = torch.nn.Sequential(torch.nn.Linear(5, 3), torch.nn.LayerNorm(3))
         fg = FlatGradients(lin.parameters())
-        # every parameter's .grad is a view into the flat buffer, in parameter order
-        off = 0
-        for p in lin.parameters():
-            assert p.grad.data_ptr() == fg.flat.data_ptr() + 4 * off and p.grad.shape == p.shape
-            off += p.numel()
+        # every parameter's .grad is a view into the flat buffer, in parameter order, each on a 256-byte boundary
+        for p, off in zip(lin.parameters(), fg.offsets):
+            assert p.grad.data_ptr() == fg.flat.data_ptr() + 4 * off and p.grad.shape == p.shape and off % 64 == 0
+        assert fg.offsets == sorted(fg.offsets) and fg.flat.numel() >= sum(p.numel() for p in lin.parameters())
         for i, p in enumerate(lin.parameters()):
             p.grad.fill_(float(rank + 1) * (i + 1))
         fg.all_reduce()

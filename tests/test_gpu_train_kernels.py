@@ -252,3 +252,27 @@ def test_gemm_tn(T, M, N, K):
     assert _rel(out, ref) <= 1e-5
     assert _rel(cs, a[:, :N].double().sum(0)) <= 1e-5, "bias gradient from the same pass"
     assert torch.equal(out, T.gemm_tn(a, b, M, N, K)), "deterministic"
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,H,hd", [(70, 3, 64), (33, 2, 32), (50, 2, 96), (20, 1, 128), (1, 1, 64)])
+def test_qk_norm_backward(T, dt, M, H, hd):
+    D = H * hd
+    qkv = (_rand(M, 3 * D, seed=61) * 1.5 + 0.3).to(dt)
+    dy = _rand(M, 3 * D + 8, seed=62).to(dt)[:, :3 * D]            # a strided view, like the parallel block's buffer
+    qw, qb = 1 + 0.2 * _rand(hd, seed=63), 0.1 * _rand(hd, seed=64)
+    kw, kb = 1 + 0.2 * _rand(hd, seed=65), 0.1 * _rand(hd, seed=66)
+    x64 = qkv.double().requires_grad_(True)
+    p64 = [t.double().requires_grad_(True) for t in (qw, qb, kw, kb)]
+    q, k, v = x64.reshape(M, 3, H, hd).unbind(1)
+    out = torch.stack((F.layer_norm(q, (hd,), p64[0], p64[1], 1e-5), F.layer_norm(k, (hd,), p64[2], p64[3], 1e-6), v), 1)
+    out.reshape(M, 3 * D).backward(dy.double())
+    d = dy.clone() if False else dy        # in place on the view
+    base = d.clone()
+    outs = [torch.full((hd,), float("nan"), device=DEV) for _ in range(4)]
+    T.qk_norm_bwd(qkv, d, M, H, hd, qw, 1e-5, kw, 1e-6, *outs)
+    tol = 1e-4 if dt == torch.float32 else 2e-2
+    assert _rel(d[:, :2 * D], x64.grad[:, :2 * D]) <= tol
+    assert torch.equal(d[:, 2 * D:], base[:, 2 * D:]), "v gradients untouched"
+    for got, ref in zip(outs, p64):
+        assert _rel(got, ref.grad) <= 1e-4

@@ -253,3 +253,102 @@ def test_flat_adamw_state_reloads_and_detached_parameters_fall_back():
     assert opt_c._flat is None
     for (k, pa), (_, pc) in zip(a.named_parameters(), c.named_parameters()):
         assert torch.equal(pa, pc), k
+
+
+# ---- attention variants and the parallel block: gradients against float64 autograd of the CPU oracle ------------------
+def _randomise(model, seed):
+    torch.manual_seed(seed)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if n.endswith("gamma") or "norm" in n and n.endswith("weight"):
+                p.copy_(1.0 + 0.1 * torch.randn_like(p))
+            elif n.endswith("bias"):
+                p.normal_(0, 0.1)
+
+
+def _check_grads(model, sd64, loss, loss64, bf16):
+    if bf16:
+        assert abs(loss.item() - loss64.item()) <= 1e-2 * abs(loss64.item())
+    else:
+        assert abs(loss.item() - loss64.item()) <= 1e-4 * abs(loss64.item())
+    gmax = max(sd64[k].grad.abs().max().item() for k, _ in model.named_parameters())
+    for k, p in model.named_parameters():
+        ref = sd64[k].grad
+        assert ref is not None and p.grad is not None and torch.isfinite(p.grad).all(), k
+        if ref.abs().max().item() < 1e-9 * gmax:
+            # mathematically zero (k_norm.bias: a shift common to every key leaves the softmax unchanged)
+            assert p.grad.abs().max().item() <= (1e-3 if bf16 else 1e-5) * gmax, k
+            continue
+        if bf16:
+            c = _cos(p.grad.cpu(), ref)
+            assert c >= (0.99 if p.numel() >= 1000 else 0.95), f"{k}: cosine {c:.4f}"
+        else:
+            err = (p.grad.cpu().double() - ref).abs().max().item() / max(ref.abs().max().item(), 1e-12)
+            assert err <= 2e-4, f"{k}: {err:.3g}"
+
+
+@pytest.mark.parametrize("bf16", [False, True])
+def test_training_with_qk_norm_and_qkv_bias(monkeypatch, bf16):
+    """Sequential blocks whose attention has qkv_bias=True and qk_norm=True (models.py:54-55,82): backward through the
+    per-head LayerNorm of q and k."""
+    from oracle import vit_oracle as O
+    from vitm_amd import training
+    from vitm_amd.models import Attention, VisionTransformer, VITC
+    LN = nn.LayerNorm
+    vt = VisionTransformer(32, patch_size=8, num_classes=10, num_heads=2, mlp_ratio=2.0, depth=2, embed_dim=128,
+                           norm_layer=LN, final_norm_layer=LN)
+    for blk in vt.blocks:
+        blk.attn = Attention(128, num_heads=2, qkv_bias=True, qk_norm=True)
+    model = VITC(vt).train()
+    _randomise(model, 11)
+    sd64 = {k: v.detach().double().requires_grad_(True) for k, v in model.state_dict().items()}
+    x = torch.randn(4, 3, 32, 32)
+    x = x.to(torch.bfloat16) if bf16 else x
+    y = torch.tensor([1, 0, 9, 3])
+    monkeypatch.setattr(O, "_t", lambda sd, key, dtype: None if sd.get(key) is None else sd[key].to(dtype))
+    ocfg = dict(image_size=(32, 32), patch_size=(8, 8), num_heads=2, depth=2)
+    loss64 = torch.nn.functional.cross_entropy(O.vitc_forward(x.double(), sd64, ocfg, dtype=torch.float64), y)
+    loss64.backward()
+    assert sd64["vit_model.blocks.0.attn.q_norm.weight"].grad is not None
+    model = model.cuda()
+    loss = training.CrossEntropyLoss()(model(x.cuda()), y.cuda())
+    loss.backward()
+    _check_grads(model, sd64, loss, loss64, bf16)
+
+
+@pytest.mark.parametrize("bf16", [False, True])
+def test_training_parallel_blocks(monkeypatch, bf16):
+    """VisionTransformer(parallel_block=True): one step through Trainer-free autograd against float64 autograd of the
+    oracle's parallel_block (parallel_block.py:193-221); hidden width 89 (not a multiple of 8) exercises the padding."""
+    from oracle import vit_oracle as O
+    from vitm_amd import training
+    from vitm_amd.models import VisionTransformer, VITC
+    LN = nn.LayerNorm
+    vt = VisionTransformer(32, patch_size=8, num_classes=7, num_heads=2, mlp_ratio=0.7, depth=2, embed_dim=128,
+                           norm_layer=LN, final_norm_layer=LN, parallel_block=True)
+    model = VITC(vt).train()
+    _randomise(model, 12)
+    sd64 = {k: v.detach().double().requires_grad_(True) for k, v in model.state_dict().items()}
+    x = torch.randn(3, 3, 32, 32)
+    x = x.to(torch.bfloat16) if bf16 else x
+    y = torch.tensor([1, 0, 6])
+    monkeypatch.setattr(O, "_t", lambda sd, key, dtype: None if sd.get(key) is None else sd[key].to(dtype))
+    cfg = dict(image_size=32, patch_size=(8, 8), num_heads=2)
+    f = O.forward_features(x.double(), sd64, cfg, "vit_model.", dtype=torch.float64)
+    for i in range(2):
+        f = O.parallel_block(f, sd64, 2, f"vit_model.blocks.{i}.", dtype=torch.float64)
+    emb = O.layer_norm(f, sd64["vit_model.norm_final.weight"], sd64["vit_model.norm_final.bias"])
+    loss64 = torch.nn.functional.cross_entropy(emb[:, 0] @ sd64["head.weight"].t() + sd64["head.bias"], y)
+    loss64.backward()
+    model = model.cuda()
+    assert training.supported(model) is None
+    loss = training.CrossEntropyLoss()(model(x.cuda()), y.cuda())
+    loss.backward()
+    _check_grads(model, sd64, loss, loss64, bf16)
+    # and a Trainer step on the same model (gradients in place, flat AdamW) runs and lowers the loss on this batch
+    opt = training.AdamW(model.parameters(), lr=1e-3)
+    tr = training.Trainer(model, opt, None, max_norm=1.0)
+    l0 = tr.step(x.cuda(), y.cuda()).item()
+    for _ in range(3):
+        l1 = tr.step(x.cuda(), y.cuda()).item()
+    assert l1 < l0

@@ -354,6 +354,122 @@ void launch_ln_bwd(const void* x, int64_t ldx, const void* dy, int64_t lddy, con
   hipLaunchKernelGGL(layernorm_bwd_kernel<T>, grid, blk, 0, st, xp, ldx, gp, lddy, w, eps, ap, ldadd, op, lddx, dwp, dbp, M, D);
 }
 
+// ---- backward of the per-head LayerNorm of q and k (Attention(qk_norm=True), parallel block) ------------------------
+// A "vector" is one head of one token: HD elements, 8 per lane on HD / 8 lanes of an SL-lane group.  blockIdx.y picks
+// q (0) or k (1); a thread walks vectors with a fixed lane-in-group, so it sums the parameter gradients of its own 8
+// elements in registers.  dqkv holds d(loss)/d(normalised q, k) on entry and d(loss)/d(q, k) on return (v untouched).
+template <typename T, int HD>
+__global__ __launch_bounds__(256) void qk_norm_bwd_kernel(const T* __restrict__ qkv, int64_t ld, T* __restrict__ dqkv,
+                                                          int64_t ldd, int64_t nvec, int H, const float* __restrict__ qw,
+                                                          float qeps, const float* __restrict__ kw, float keps,
+                                                          float* __restrict__ partial) {
+  constexpr int LPV = HD / 8;
+  constexpr int SL = LPV <= 4 ? 4 : (LPV <= 8 ? 8 : 16);
+  constexpr int GPB = 256 / SL;                 // lane groups per workgroup
+  __shared__ float red[2][GPB][HD];
+  const bool isk = blockIdx.y != 0;
+  const int grp = threadIdx.x / SL, sub = threadIdx.x % SL;
+  const bool lane_live = sub < LPV;
+  const float eps = isk ? keps : qeps;
+  float wv[8], gw[8], gb[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    wv[e] = lane_live ? (isk ? kw : qw)[sub * 8 + e] : 0.f;
+    gw[e] = 0.f;
+    gb[e] = 0.f;
+  }
+  const int64_t coloff = isk ? (int64_t)H * HD : 0;
+  const float inv = 1.0f / (float)HD;
+  // every lane of a group runs the same number of iterations (the shuffles need them all)
+  for (int64_t vec = (int64_t)blockIdx.x * GPB + grp; vec < nvec; vec += (int64_t)gridDim.x * GPB) {
+    const int64_t m = vec / H;
+    const int h = (int)(vec - m * H);
+    const int64_t off = coloff + (int64_t)h * HD + sub * 8;
+    float x[8], g[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] = g[e] = 0.f;
+    if (lane_live) {
+      ld8(qkv + m * ld + off, x);
+      ld8(dqkv + m * ldd + off, g);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s += x[e];
+#pragma unroll
+    for (int o = 1; o < SL; o <<= 1) s += __shfl_xor(s, o, 64);
+    const float mean = s * inv;
+    float q = 0.f;
+    if (lane_live) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) q = fmaf(x[e] - mean, x[e] - mean, q);
+    }
+#pragma unroll
+    for (int o = 1; o < SL; o <<= 1) q += __shfl_xor(q, o, 64);
+    const float rstd = 1.0f / sqrtf(q * inv + eps);
+    float c1 = 0.f, c2 = 0.f;
+    if (lane_live) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float xh = (x[e] - mean) * rstd;
+        gw[e] = fmaf(g[e], xh, gw[e]);
+        gb[e] += g[e];
+        const float gg = g[e] * wv[e];
+        x[e] = xh;
+        g[e] = gg;
+        c1 += gg;
+        c2 = fmaf(gg, xh, c2);
+      }
+    }
+#pragma unroll
+    for (int o = 1; o < SL; o <<= 1) {
+      c1 += __shfl_xor(c1, o, 64);
+      c2 += __shfl_xor(c2, o, 64);
+    }
+    c1 *= inv;
+    c2 *= inv;
+    if (lane_live) {
+      float r[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) r[e] = rstd * (g[e] - c1 - x[e] * c2);
+      st8(dqkv + m * ldd + off, r);
+    }
+  }
+  // per-workgroup partial sums: partial[(2 isk + which) * gridDim.x + blockIdx.x][HD]
+#pragma unroll
+  for (int e = 0; e < 8; ++e)
+    if (lane_live) {
+      red[0][grp][sub * 8 + e] = gw[e];
+      red[1][grp][sub * 8 + e] = gb[e];
+    }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * HD; i += 256) {
+    const int which = i / HD, c = i - which * HD;
+    float t = 0.f;
+    for (int gi = 0; gi < GPB; ++gi) t += red[which][gi][c];
+    partial[((int64_t)(2 * (isk ? 1 : 0) + which) * gridDim.x + blockIdx.x) * HD + c] = t;
+  }
+}
+
+template <typename T>
+int launch_qk_norm_bwd(const void* qkv, int64_t ld, void* dqkv, int64_t ldd, int M, int H, int hd, const float* qw,
+                       float qeps, const float* kw, float keps, float* partial, int nblocks, hipStream_t st) {
+  const int64_t nvec = (int64_t)M * H;
+  const dim3 grid((unsigned)nblocks, 2), blk(256);
+#define VITM_QKB(HDV) hipLaunchKernelGGL((qk_norm_bwd_kernel<T, HDV>), grid, blk, 0, st, (const T*)qkv, ld, (T*)dqkv, ldd, nvec, H, qw, qeps, kw, keps, partial)
+  switch (hd) {
+    case 32: VITM_QKB(32); break;
+    case 64: VITM_QKB(64); break;
+    case 96: VITM_QKB(96); break;
+    case 128: VITM_QKB(128); break;
+    default:
+      vitm_set_error("vitm_qk_norm_bwd: head_dim=%d unsupported (32, 64, 96, 128)", hd);
+      return VITM_EUNSUPPORTED;
+  }
+#undef VITM_QKB
+  VITM_CHECK_LAUNCH("vitm_qk_norm_bwd");
+  return VITM_OK;
+}
+
 // ---- GELU backward: eight elements per thread when the rows allow 16-byte accesses ---------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void gelu_bwd8_kernel(const T* __restrict__ pre, int64_t ldp, const T* __restrict__ dh,
@@ -552,6 +668,22 @@ extern "C" int vitm_layernorm_bwd(const void* x, int64_t ldx, const void* dy, in
   else launch_ln_bwd<bf16_t>(x, ldx, dy, lddy, w, eps, dx_add, ldadd, dx, lddx, dw_partial, db_partial, nblocks, M, D, (hipStream_t)stream);
   VITM_CHECK_LAUNCH("vitm_layernorm_bwd");
   return VITM_OK;
+}
+
+extern "C" int vitm_qk_norm_bwd(const void* qkv, int64_t ldqkv, void* dqkv, int64_t lddqkv, int dtype, int M, int H,
+                                int head_dim, const float* q_w, float q_eps, const float* k_w, float k_eps, float* partial,
+                                int nblocks, vitm_stream_t stream) {
+  VITM_REQUIRE(qkv && dqkv && q_w && k_w && partial, "vitm_qk_norm_bwd: null pointer");
+  VITM_REQUIRE(dtype == VITM_BF16 || dtype == VITM_F32, "vitm_qk_norm_bwd: bad dtype %d", dtype);
+  VITM_REQUIRE(M > 0 && H > 0 && nblocks > 0 && nblocks < 65536, "vitm_qk_norm_bwd: bad shape");
+  const int64_t D = (int64_t)H * head_dim;
+  VITM_REQUIRE(ldqkv >= 3 * D && lddqkv >= 3 * D, "vitm_qk_norm_bwd: leading dimensions must cover 3*H*head_dim");
+  const bool ok = dtype == VITM_F32 ? vec_ok<float>(qkv, ldqkv) && vec_ok<float>(dqkv, lddqkv)
+                                    : vec_ok<bf16_t>(qkv, ldqkv) && vec_ok<bf16_t>(dqkv, lddqkv);
+  VITM_REQUIRE(ok, "vitm_qk_norm_bwd: rows must start 16-byte aligned");
+  if (dtype == VITM_F32)
+    return launch_qk_norm_bwd<float>(qkv, ldqkv, dqkv, lddqkv, M, H, head_dim, q_w, q_eps, k_w, k_eps, partial, nblocks, (hipStream_t)stream);
+  return launch_qk_norm_bwd<bf16_t>(qkv, ldqkv, dqkv, lddqkv, M, H, head_dim, q_w, q_eps, k_w, k_eps, partial, nblocks, (hipStream_t)stream);
 }
 
 extern "C" int vitm_gelu_bwd(const void* pre, int64_t ldp, const void* dh, int64_t ldh, void* dpre, int64_t ldd, int dtype, int M,

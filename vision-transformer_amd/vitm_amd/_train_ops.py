@@ -116,6 +116,21 @@ def layernorm_bwd(x, dy, w, eps, M, D, dx, dx_add=None, dw_out=None, db_out=None
         colsum(dbp, nb, D, out=db_out)
 
 
+QK_NORM_BWD_BLOCKS = 256
+
+
+def qk_norm_bwd(qkv_pre, dqkv, M, H, hd, q_w, q_eps, k_w, k_eps, dqw_out, dqb_out, dkw_out, dkb_out) -> None:
+    """In place on dqkv: gradients wrt the normalised q, k become gradients wrt the pre-norm q, k; the four parameter
+    gradients (head_dim floats each) go to the *_out tensors."""
+    nb = min(QK_NORM_BWD_BLOCKS, max(1, (M * H + 63) // 64))
+    part = torch.empty((4, nb, hd), dtype=F32, device=dqkv.device)
+    _lib.check(_lib.load().vitm_qk_norm_bwd(_p(qkv_pre), qkv_pre.stride(0), _p(dqkv), dqkv.stride(0), _rm(qkv_pre, dqkv), M, H,
+                                            hd, _p(_f32(q_w)), float(q_eps), _p(_f32(k_w)), float(k_eps), _p(part), nb,
+                                            _stream()), "vitm_qk_norm_bwd")
+    for i, out in enumerate((dqw_out, dqb_out, dkw_out, dkb_out)):
+        colsum(part[i], nb, hd, out=out)
+
+
 def gelu_bwd(pre, dh, dpre, M, D) -> None:
     _lib.check(_lib.load().vitm_gelu_bwd(_p(pre), pre.stride(0), _p(dh), dh.stride(0), _p(dpre), dpre.stride(0),
                                          _rm(pre, dh, dpre), M, D, _stream()), "vitm_gelu_bwd")

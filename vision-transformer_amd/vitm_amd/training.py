@@ -15,9 +15,9 @@ operands are bf16 on the bf16 matrix cores with fp32 accumulation (weight gradie
 the accumulators).  PyTorch supplies memory, the autograd hook-up (one ``autograd.Function`` for the whole model, one
 for the loss) and, for data parallelism, the RCCL all-reduce of the flat gradient buffer.
 
-Supported: ``VITC(VisionTransformer)`` built from this package's sequential ``Block`` with LayerNorm (or Identity)
-norms, learnable position embedding, GELU MLP, no qk-norm -- the configuration the reference's training script builds
-(train.py:167-177).
+Supported: ``VITC(VisionTransformer)`` built from this package's sequential ``Block`` (the configuration the
+reference's training script builds, train.py:167-177; LayerNorm or Identity norms, ``qk_norm`` / ``qkv_bias`` attention)
+or from ``ParallelBlock`` (``VisionTransformer(parallel_block=True)``), with a learnable position embedding and GELU.
 """
 from __future__ import annotations
 
@@ -29,6 +29,7 @@ import torch.nn as nn
 from . import _ops
 from . import _train_ops as T
 from .models.models import Block, VisionTransformer, _check_gelu
+from .models.parallel_block import ParallelBlock
 from .models.patch_embeddings import PatchEmbed, layernorm_params
 
 F32 = torch.float32
@@ -69,11 +70,46 @@ def supported(model) -> Optional[str]:
     if vt.pos_embed is None:
         return "a learnable position embedding is required"
     for blk in vt.blocks:
+        if type(blk) is ParallelBlock:
+            continue
         if type(blk) is not Block:
-            return f"block type {type(blk).__name__} has no backward yet"
-        if blk.attn.qk_norm or blk.mlp.use_conv:
-            return "Attention(qk_norm=True) / MLP(use_conv=True) have no backward yet"
+            return f"block type {type(blk).__name__} has no backward"
+        if blk.mlp.use_conv:
+            return "MLP(use_conv=True) has no HIP path"
     return None
+
+
+def _qk_norms(attn, what: str):
+    """(q_norm, k_norm) as _ln tuples, or None when the attention has no q/k LayerNorm."""
+    qn, kn = _ln(attn.q_norm, what + ".q_norm"), _ln(attn.k_norm, what + ".k_norm")
+    if (qn is None) != (kn is None):
+        raise NotImplementedError("q_norm and k_norm must both be LayerNorm or both Identity")
+    return (qn, kn) if qn is not None else None
+
+
+def _attention_forward(attn, qkv_pre: torch.Tensor, o: torch.Tensor, B: int, N: int, what: str, s: dict) -> None:
+    """Fused attention on [M, 3D] q|k|v rows with the optional per-head q/k LayerNorm; keeps what the backward needs
+    (the q|k|v the kernel saw, the pre-norm copy when there is a norm, the log-sum-exp)."""
+    H, hd = attn.num_heads, attn.head_dim
+    qk = _qk_norms(attn, what)
+    qkv = qkv_pre
+    if qk is not None:
+        qkv = qkv_pre.clone()
+        _ops.qk_norm(qkv, B * N, H, hd, qk[0][0], qk[0][1], qk[0][2], qk[1][0], qk[1][1], qk[1][2])
+        s["qkv_pre"] = qkv_pre
+    lse = torch.empty(B * H * N, dtype=F32, device=qkv.device)
+    T.attention_lse(qkv, o, lse, B, N, H, hd, hd ** -0.5)
+    s.update(qkv=qkv, o=o, lse=lse)
+
+
+def _attention_backward(G, attn, s: dict, d_o: torch.Tensor, dqkv: torch.Tensor, B: int, N: int, what: str) -> None:
+    """dqkv (an [M, >= 3D] view) <- gradient wrt the q|k|v rows the projection produced."""
+    H, hd = attn.num_heads, attn.head_dim
+    T.attention_bwd(s["qkv"], s["o"], d_o, s["lse"], dqkv, B, N, H, hd, hd ** -0.5)
+    qk = _qk_norms(attn, what)
+    if qk is not None:
+        T.qk_norm_bwd(s["qkv_pre"], dqkv, B * N, H, hd, qk[0][0], qk[0][2], qk[1][0], qk[1][2],
+                      G.buf(qk[0][3]), G.buf(qk[0][4]), G.buf(qk[1][3]), G.buf(qk[1][4]))
 
 
 # ----------------------------------------------------------------------------------------------------------------
@@ -94,8 +130,7 @@ def _block_forward(blk: Block, x: torch.Tensor, B: int, N: int) -> (torch.Tensor
     qkv = torch.empty((M, 3 * D), dtype=cd, device=dev)
     _ops.gemm(n1, _pk(attn.qkv.weight, attn.qkv.bias, cd), qkv, _ops.EPI_BIAS, M)
     o = _buf(M, D, dev, cd)
-    lse = torch.empty(B * H * N, dtype=F32, device=dev)
-    T.attention_lse(qkv, o, lse, B, N, H, hd, attn.scale)
+    _attention_forward(attn, qkv, o, B, N, "Attention", s)
     z1 = torch.empty((M, _ops.round_up(D, 8)), dtype=cd, device=dev)
     _ops.gemm(o, _pk(attn.proj.weight, attn.proj.bias, cd), z1, _ops.EPI_BIAS, M)
     x1 = _buf(M, D, dev, cd)
@@ -113,7 +148,7 @@ def _block_forward(blk: Block, x: torch.Tensor, B: int, N: int) -> (torch.Tensor
     _ops.gemm(h, _pk(mlp.linear_layer2.weight, mlp.linear_layer2.bias, cd), z2, _ops.EPI_BIAS, M)
     x2 = _buf(M, D, dev, cd)
     T.residual_scale(x1, z2, _ops.f32vec(blk.ls2.gamma), x2, M, D)
-    s.update(qkv=qkv, o=o, lse=lse, z1=z1, x1=x1, pre=pre, h=h, z2=z2)
+    s.update(z1=z1, x1=x1, pre=pre, h=h, z2=z2)
     return x2, s
 
 
@@ -154,7 +189,7 @@ def forward_train(model, img: torch.Tensor, compute_dtype: Optional[torch.dtype]
                         npre[0] if npre else None, npre[1] if npre else None, npre[2] if npre else 0.0)
     S["blocks"] = []
     for blk in vt.blocks:
-        x, s = _block_forward(blk, x, B, N)
+        x, s = (_pblock_forward if type(blk) is ParallelBlock else _block_forward)(blk, x, B, N)
         S["blocks"].append(s)
     S["xL"] = x
     ld = x.shape[1]
@@ -227,7 +262,7 @@ def _block_backward(G: _Grads, blk: Block, s: dict, dx2: torch.Tensor, B: int, N
     _ops.scale_channels(dx1[:, :dz1.shape[1]] if dx1.shape[1] != dz1.shape[1] else dx1, dz1, M, _ops.round_up(D, 8), _pad8(g1))
     d_o = _linear_backward(G, attn.proj, dz1, s["o"], M)
     dqkv = torch.empty((M, 3 * D), dtype=cd, device=dev)
-    T.attention_bwd(s["qkv"], s["o"], d_o, s["lse"], dqkv, B, N, H, hd, attn.scale)
+    _attention_backward(G, attn, s, d_o, dqkv, B, N, "Attention")
     n1 = s["x"]
     if ln1 is not None:
         n1 = n2 if ln2 is not None else _buf(M, D, dev, cd)
@@ -238,6 +273,67 @@ def _block_backward(G: _Grads, blk: Block, s: dict, dx2: torch.Tensor, B: int, N
         T.layernorm_bwd(s["x"], dn1, ln1[0], ln1[2], M, D, dx, dx_add=dx1, dw_out=G.buf(ln1[3]), db_out=G.buf(ln1[4]))
     else:
         _add(dx1, dn1, dx, M, D)
+    return dx
+
+
+# ---- ViT-22B style parallel block (parallel_block.py:193-221) --------------------------------------------------------
+def _pblock_forward(blk: ParallelBlock, x: torch.Tensor, B: int, N: int) -> (torch.Tensor, dict):
+    D, M, dev, cd = blk.dim, B * N, x.device, x.dtype
+    blk.attn._check()
+    _check_gelu(blk.mlp.act_layer, "ParallelBlock.mlp")
+    if D % 8 != 0:
+        raise NotImplementedError("ParallelBlock on the HIP path needs dim % 8 == 0")
+    hid = blk.mlp_hidden_dim
+    ln = _ln(blk.norm, "ParallelBlock.norm")
+    s = {"x": x}
+    n = x
+    if ln is not None:
+        n = _buf(M, D, dev, cd)
+        _ops.layernorm(x, n, M, D, ln[0], ln[1], ln[2])
+    w1, b1 = blk.fused_proj_1.weight, blk.fused_proj_1.bias
+    qkv = torch.empty((M, 3 * D), dtype=cd, device=dev)
+    _ops.gemm(n, _pk(w1[:3 * D], b1[:3 * D] if b1 is not None else None, cd), qkv, _ops.EPI_BIAS, M)
+    pre = _buf(M, hid, dev, cd)
+    _ops.gemm(n, _pk(w1[3 * D:], b1[3 * D:] if b1 is not None else None, cd), pre, _ops.EPI_BIAS, M)
+    h = _buf(M, hid, dev, cd)
+    _ops.gelu(pre, h, M, _ops.round_up(hid, 8))
+    o = _buf(M, D, dev, cd)
+    _attention_forward(blk.attn, qkv, o, B, N, "ParallelBlockMultiHeadAttention", s)
+    cat = _buf(M, 2 * D, dev, cd)                            # attention half | MLP half: the concat is free
+    _ops.gemm(o, _pk(blk.attn.proj.weight, blk.attn.proj.bias, cd), cat[:, :D], _ops.EPI_BIAS, M)
+    _ops.gemm(h, _pk(blk.mlp.out_proj.weight, blk.mlp.out_proj.bias, cd), cat[:, D:2 * D], _ops.EPI_BIAS, M)
+    z = torch.empty((M, D), dtype=cd, device=dev)
+    _ops.gemm(cat, _pk(blk.fused_proj_2.weight, blk.fused_proj_2.bias, cd), z, _ops.EPI_BIAS, M)
+    x2 = _buf(M, D, dev, cd)
+    T.residual_scale(x, z, _ops.f32vec(blk.layer_scale.gamma), x2, M, D)
+    s.update(n=n, pre=pre, h=h, cat=cat, z=z)
+    return x2, s
+
+
+def _pblock_backward(G: _Grads, blk: ParallelBlock, s: dict, dx2: torch.Tensor, B: int, N: int) -> torch.Tensor:
+    D, M, dev, cd = blk.dim, B * N, dx2.device, dx2.dtype
+    hid = blk.mlp_hidden_dim
+    ln = _ln(blk.norm, "ParallelBlock.norm")
+    gam = _ops.f32vec(blk.layer_scale.gamma)
+    # x2 = x + gamma * z, z = fused_proj_2(cat)
+    T.colsum(dx2, M, D, s["z"], out=G.buf(blk.layer_scale.gamma))
+    dz = torch.empty((M, D), dtype=cd, device=dev)
+    _ops.scale_channels(dx2[:, :D] if dx2.shape[1] != D else dx2, dz, M, D, gam)
+    dcat = _linear_backward(G, blk.fused_proj_2, dz, s["cat"], M)                 # [M, >= 2D]
+    # attention half: cat[:, :D] = attn.proj(o)
+    d_o = _linear_backward(G, blk.attn.proj, dcat[:, :D], s["o"], M)
+    # MLP half: cat[:, D:2D] = out_proj(gelu(pre))
+    dh = _linear_backward(G, blk.mlp.out_proj, dcat[:, D:2 * D], s["h"], M)
+    # gradient of the fused first projection's output, [q | k | v | hidden] side by side like its weight rows
+    d1 = _buf(M, 3 * D + hid, dev, cd)
+    T.gelu_bwd(s["pre"], dh, d1[:, 3 * D:3 * D + hid], M, hid)
+    _attention_backward(G, blk.attn, s, d_o, d1[:, :3 * D], B, N, "ParallelBlockMultiHeadAttention")
+    dn = _linear_backward(G, blk.fused_proj_1, d1, s["n"], M)
+    dx = _buf(M, D, dev, cd)
+    if ln is not None:
+        T.layernorm_bwd(s["x"], dn, ln[0], ln[2], M, D, dx, dx_add=dx2, dw_out=G.buf(ln[3]), db_out=G.buf(ln[4]))
+    else:
+        _add(dx2, dn, dx, M, D)
     return dx
 
 
@@ -285,7 +381,7 @@ def backward_train(model, S: dict, dlogits: torch.Tensor, sink=None) -> Dict[nn.
 
     # ---- blocks, last to first
     for blk, s in zip(reversed(list(vt.blocks)), reversed(S["blocks"])):
-        dx = _block_backward(G, blk, s, dx, B, N)
+        dx = (_pblock_backward if type(blk) is ParallelBlock else _block_backward)(G, blk, s, dx, B, N)
 
     # ---- x0 = LN_pre(xcat) + pos ; xcat = [cls ; LN_e(tok)] ; tok = im2col(img) Wpe^T (+ b)
     dpos = T.colsum(dx.view(B, N * ld), B, N * ld)         # sum over the batch
@@ -380,20 +476,31 @@ class CrossEntropyLoss(nn.Module):
 # ----------------------------------------------------------------------------------------------------------------
 # gradients in one flat buffer, clipping, AdamW, data-parallel all-reduce
 # ----------------------------------------------------------------------------------------------------------------
+FLAT_ALIGN = 64     # floats: every tensor starts on a 256-byte boundary of the flat buffer (kernels use 16-byte accesses)
+
+
+def _flat_layout(params):
+    """(offsets, total) in floats of the tensors laid end to end, each start rounded up to FLAT_ALIGN; the gaps stay
+    zero for ever (zero gradient, zero moments, zero parameter: AdamW maps that to zero)."""
+    offsets, off = [], 0
+    for p in params:
+        offsets.append(off)
+        off += (p.numel() + FLAT_ALIGN - 1) // FLAT_ALIGN * FLAT_ALIGN
+    return offsets, off
+
+
 class FlatGradients:
     """Every parameter's ``.grad`` as a view into one flat fp32 buffer: one kernel clips them all, one collective
     all-reduces them all.  ``zero()`` replaces ``optimizer.zero_grad()``."""
 
     def __init__(self, params):
         self.params = [p for p in params if p.requires_grad]
-        total = sum(p.numel() for p in self.params)
+        self.offsets, total = _flat_layout(self.params)
         dev = self.params[0].device
         self.flat = torch.zeros(total, dtype=F32, device=dev)
         self.views = {}
-        off = 0
-        for p in self.params:
+        for p, off in zip(self.params, self.offsets):
             p.grad = self.views[p] = self.flat[off:off + p.numel()].view(p.shape)
-            off += p.numel()
 
     def attach(self) -> None:
         """Make every ``.grad`` the view into the flat buffer again (``zero_grad(set_to_none=True)`` drops them)."""
@@ -402,12 +509,9 @@ class FlatGradients:
                 p.grad = self.views[p]
 
     def zero(self) -> None:
+        """Replaces ``optimizer.zero_grad()``."""
         self.flat.zero_()
-        off = 0
-        for p in self.params:                  # re-attach views that zero_grad(set_to_none=True) may have dropped
-            if p.grad is None or p.grad.data_ptr() != self.flat.data_ptr() + 4 * off:
-                p.grad = self.flat[off:off + p.numel()].view(p.shape)
-            off += p.numel()
+        self.attach()
 
     def clip_grad_norm_(self, max_norm: float) -> torch.Tensor:
         """torch.nn.utils.clip_grad_norm_ (train.py:222): returns the total norm (a device scalar)."""
@@ -435,17 +539,13 @@ class FlatParameters:
         self.params = [p for p in params if p.requires_grad]
         if any(p.dtype != F32 or not p.is_cuda for p in self.params):
             raise TypeError("FlatParameters holds fp32 CUDA parameters")
-        total = sum(p.numel() for p in self.params)
-        self.flat = torch.empty(total, dtype=F32, device=self.params[0].device)
-        self.offsets = []
-        off = 0
+        self.offsets, total = _flat_layout(self.params)
+        self.flat = torch.zeros(total, dtype=F32, device=self.params[0].device)
         with torch.no_grad():
-            for p in self.params:
+            for p, off in zip(self.params, self.offsets):
                 v = self.flat[off:off + p.numel()].view(p.shape)
                 v.copy_(p.data)
                 p.data = v
-                self.offsets.append(off)
-                off += p.numel()
 
     def intact(self) -> bool:
         base = self.flat.data_ptr()
@@ -468,7 +568,8 @@ class AdamW(torch.optim.Optimizer):
             return False
         ps = self.param_groups[0]["params"]
         if len(ps) != len(params.params) or any(a is not b for a, b in zip(ps, params.params)) \
-                or len(ps) != len(grads.params) or any(a is not b for a, b in zip(ps, grads.params)):
+                or len(ps) != len(grads.params) or any(a is not b for a, b in zip(ps, grads.params)) \
+                or params.offsets != grads.offsets:
             return False
         m, v = torch.zeros_like(params.flat), torch.zeros_like(params.flat)
         self._flat = (params, grads, m, v)
