@@ -8,47 +8,51 @@
 //
 // The output is small (a weight matrix) and the reduction is long (every token of the batch), so the reduction is split
 // over workgroup slices: each slice writes its own fp32 partial tile and a second kernel adds the slices in a
-// fixed order (deterministic; no atomics).  Workgroup = 4 waves, 128 x 128 output tile, 64 x 64 per wave as 2 x 2
-// v_mfma_f32_32x32x16_bf16 tiles; the global loads of the next 64-row step are in flight while the current one is
+// fixed order (deterministic; no atomics).  Workgroup = 8 (or 4) waves, 256 (or 128) x 128 output tile, 64 x 64 per
+// wave as 2 x 2 v_mfma_f32_32x32x16_bf16 tiles; the global loads of the next 64-row step are in flight while the current one is
 // multiplied (register staging, two LDS buffers, one barrier per step).
 #include "common.h"
 
 namespace {
 
-constexpr int TN_BN = 128;            // output rows (columns of a) per workgroup
 constexpr int TN_BK = 128;            // output columns (columns of b) per workgroup
 constexpr int TN_BM = 64;             // reduction rows per step
-// LDS row stride in bytes: 256 + 64, so the four rows a transposing read touches per half-wave (4 x 64 bytes) fall
-// in four different quarters of the 64 banks
-constexpr int TN_RS = TN_BN * 2 + 64;
-constexpr int TN_TILE = TN_BM * TN_RS;
-constexpr int TN_TARGET_WGS = 768;    // workgroups wanted in flight (256 CUs x 2 resident + slack)
+// LDS row strides are (tile row bytes) + 64, i.e. 64 mod 256: the four rows a transposing read touches per half-wave
+// (4 x 64 bytes) then fall in four different quarters of the 64 banks (SQ_LDS_BANK_CONFLICT = 0)
 constexpr int TN_MIN_ROWS = 512;      // reduction rows a slice should at least own
+#ifndef TN_DEPTH
+#define TN_DEPTH 2                    // 64-row steps of operand loads in flight per thread
+#endif
 
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
-struct TnStage {   // one thread's share of a 64-row step of both operands
-  u32x4_t a[4], b[4];
-};
-
 __device__ __forceinline__ u16x4_t tn_tr_read(const char* lds_addr) {
   s16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(lds_addr));
   return __builtin_bit_cast(u16x4_t, v);
 }
 
+template <int RS>
 __device__ __forceinline__ bf16x8_t tn_frag(const char* a0) {
   const u16x4_t lo = tn_tr_read(a0);
-  const u16x4_t hi = tn_tr_read(a0 + 8 * TN_RS);
+  const u16x4_t hi = tn_tr_read(a0 + 8 * RS);
   u16x8_t t;
   t[0] = lo[0]; t[1] = lo[1]; t[2] = lo[2]; t[3] = lo[3];
   t[4] = hi[0]; t[5] = hi[1]; t[6] = hi[2]; t[7] = hi[3];
   return __builtin_bit_cast(bf16x8_t, t);
 }
 
-__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const bf16_t* __restrict__ a, int64_t lda,
-                                                      const bf16_t* __restrict__ b, int64_t ldb,
-                                                      float* __restrict__ dst, int64_t ldd, int64_t slice_stride,
-                                                      float* __restrict__ csum, int M, int N, int K, int rows_per_slice,
-                                                      int tiles_k, int nslices) {
+// BN_ = output rows per workgroup: 128 (4 waves as 2 x 2, two workgroups per CU) or 256 (8 waves as 4 x 2, one per CU:
+// a quarter less operand traffic per MAC, the b tile being shared by twice as many rows).  Each wave owns 64 x 64.
+template <int BN_, int DEPTH>
+__global__ __launch_bounds__(BN_ * 2, BN_ == 128 ? 2 : 1) void gemm_tn_kernel(
+    const bf16_t* __restrict__ a, int64_t lda, const bf16_t* __restrict__ b, int64_t ldb, float* __restrict__ dst,
+    int64_t ldd, int64_t slice_stride, float* __restrict__ csum, int M, int N, int K, int rows_per_slice, int tiles_k,
+    int nslices) {
+  constexpr int NT_ = BN_ * 2;                       // threads
+  constexpr int RSA = BN_ * 2 + 64, RSB = TN_BK * 2 + 64;   // LDS row strides (bytes): 64 mod 256, see TN_RS
+  constexpr int TILE_A = TN_BM * RSA, TILE_B = TN_BM * RSB, STAGE = TILE_A + TILE_B;
+  constexpr int CA = BN_ / 8, CB = TN_BK / 8;        // 16-byte chunks per tile row
+  constexpr int RPA = NT_ / CA, RPB = NT_ / CB;      // rows covered by one pass of the workgroup
+  constexpr int JA = TN_BM / RPA, JB = TN_BM / RPB;  // passes (loads per thread) per step
   extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 buffers][a tile, b tile]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, hh = lane >> 5;
@@ -57,45 +61,50 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const bf16_t* __restric
   // the slice's rows is fetched from HBM once per XCD instead of once per output tile.
   const int slice = blockIdx.x % nslices, tile = blockIdx.x / nslices;
   const int tn = tile / tiles_k, tk = tile - tn * tiles_k;
-  const int n0 = tn * TN_BN, k0 = tk * TN_BK;
+  const int n0 = tn * BN_, k0 = tk * TN_BK;
   const int m_begin = slice * rows_per_slice;
   int m_end = m_begin + rows_per_slice;
   m_end = m_end < M ? m_end : M;
   const int nsteps = (m_end - m_begin + TN_BM - 1) / TN_BM;
 
-  // staging: 1024 16-byte chunks per operand tile, four per thread, fetched with raw buffer loads whose descriptor
-  // ends at the slice's last row: rows past the slice (and the chunks of threads whose columns lie past N / K, which
-  // are given an offset beyond any descriptor) come back as zeros from the range check, with no branch, no clamp and
-  // no 64-bit address arithmetic in the loop.
-  const int srow = tid >> 4, sch = tid & 15;            // + 16 rows per j
+  // staging: 16-byte chunks fetched with raw buffer loads whose descriptor ends at the slice's last row: rows past
+  // the slice (and the chunks of threads whose columns lie past N / K, which are given an offset beyond any
+  // descriptor) come back as zeros from the range check, with no branch, no clamp and no 64-bit address arithmetic
+  // in the loop.
+  const int rowa = tid / CA, cha = tid % CA, rowb = tid / CB, chb = tid % CB;
   const int rows_here = m_end > m_begin ? m_end - m_begin : 0;
   const __amdgpu_buffer_rsrc_t ra_desc = __builtin_amdgcn_make_buffer_rsrc(
       (void*)(a + (int64_t)m_begin * lda), 0, (int)((int64_t)rows_here * lda * 2), 0x00020000);
   const __amdgpu_buffer_rsrc_t rb_desc = __builtin_amdgcn_make_buffer_rsrc(
       (void*)(b + (int64_t)m_begin * ldb), 0, (int)((int64_t)rows_here * ldb * 2), 0x00020000);
   const unsigned OOB = 0x80000000u;
-  unsigned va = n0 + sch * 8 < N ? (unsigned)((srow * lda + n0 + sch * 8) * 2) : OOB;
-  unsigned vb = k0 + sch * 8 < K ? (unsigned)((srow * ldb + k0 + sch * 8) * 2) : OOB;
-  const unsigned ja = (unsigned)(16 * lda * 2), jb = (unsigned)(16 * ldb * 2);   // 16 rows further
-  const int soff = srow * TN_RS + sch * 16;
+  unsigned va = n0 + cha * 8 < N ? (unsigned)((rowa * lda + n0 + cha * 8) * 2) : OOB;
+  unsigned vb = k0 + chb * 8 < K ? (unsigned)((rowb * ldb + k0 + chb * 8) * 2) : OOB;
+  const unsigned ja = (unsigned)(RPA * lda * 2), jb = (unsigned)(RPB * ldb * 2);
+  const int soffa = rowa * RSA + cha * 16, soffb = TILE_A + rowb * RSB + chb * 16;
+  struct Stage {   // one thread's share of a 64-row step of both operands
+    u32x4_t a[JA], b[JB];
+  };
   auto fetch = [&]() {   // the next 64 rows; advances the offsets
-    TnStage st;
+    Stage st;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < JA; ++j) {
       st.a[j] = __builtin_amdgcn_raw_buffer_load_b128(ra_desc, va, 0, 0);
-      st.b[j] = __builtin_amdgcn_raw_buffer_load_b128(rb_desc, vb, 0, 0);
       va += ja;
+    }
+#pragma unroll
+    for (int j = 0; j < JB; ++j) {
+      st.b[j] = __builtin_amdgcn_raw_buffer_load_b128(rb_desc, vb, 0, 0);
       vb += jb;
     }
     return st;
   };
-  auto stash = [&](int buf, const TnStage st) {
-    char* As = smem + buf * 2 * TN_TILE;
+  auto stash = [&](int buf, const Stage st) {
+    char* base = smem + buf * STAGE;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      *(u32x4_t*)(As + soff + 16 * j * TN_RS) = st.a[j];
-      *(u32x4_t*)(As + TN_TILE + soff + 16 * j * TN_RS) = st.b[j];
-    }
+    for (int j = 0; j < JA; ++j) *(u32x4_t*)(base + soffa + j * RPA * RSA) = st.a[j];
+#pragma unroll
+    for (int j = 0; j < JB; ++j) *(u32x4_t*)(base + soffb + j * RPB * RSB) = st.b[j];
   };
 
   f32x16_t acc[2][2];
@@ -107,9 +116,9 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const bf16_t* __restric
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
   const int g16 = lane >> 4, li = lane & 15;
-  const int tr_off = (4 * hh + (li >> 2)) * TN_RS + (16 * (g16 & 1) + 4 * (li & 3)) * 2;
+  const int trow = 4 * hh + (li >> 2), tcol = (16 * (g16 & 1) + 4 * (li & 3)) * 2;
   const int wn = wave >> 1, wk = wave & 1;
-  const int a_off = tr_off + (64 * wn) * 2, b_off = TN_TILE + tr_off + (64 * wk) * 2;
+  const int a_off = trow * RSA + tcol + (64 * wn) * 2, b_off = TILE_A + trow * RSB + tcol + (64 * wk) * 2;
   // column sums of a (the bias gradient) ride along on the workgroups of the first column tile: one more product
   // per a fragment, against a fragment of ones -- every column of that accumulator is sum_m a[m, n]
   const bool want_csum = csum != nullptr && tk == 0 && wk == 0;   // wave-uniform
@@ -123,12 +132,13 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const bf16_t* __restric
   for (int j = 0; j < 8; ++j) ones_u[j] = 0x3F80;
   const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, ones_u);
   auto compute = [&](int buf) {
-    const char* base = smem + buf * 2 * TN_TILE;
+    const char* base = smem + buf * STAGE;
 #pragma unroll
     for (int s2 = 0; s2 < TN_BM / 16; ++s2) {
-      const char* t = base + 16 * s2 * TN_RS;
-      const bf16x8_t a0 = tn_frag(t + a_off), a1 = tn_frag(t + a_off + 64);
-      const bf16x8_t b0 = tn_frag(t + b_off), b1 = tn_frag(t + b_off + 64);
+      const char* ta = base + 16 * s2 * RSA + a_off;
+      const char* tb = base + 16 * s2 * RSB + b_off;
+      const bf16x8_t a0 = tn_frag<RSA>(ta), a1 = tn_frag<RSA>(ta + 64);
+      const bf16x8_t b0 = tn_frag<RSB>(tb), b1 = tn_frag<RSB>(tb + 64);
       acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
       acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
       acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
@@ -140,16 +150,26 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const bf16_t* __restric
     }
   };
 
-  // registers hold the rows of the next two steps (R0: even steps, R1: odd steps) while LDS holds the current one
+  // LDS holds the current step (two buffers); registers hold the next DEPTH steps, so a load has DEPTH steps of
+  // multiplying to arrive in (the operands come from L2 / the Infinity Cache at ~1.5 us under this load: with one
+  // step of cover the loop ran at the speed of the loads alone).  Steps past the slice load zeros and are never used.
   if (nsteps > 0) {   // block-uniform
-    TnStage nxt = fetch();
-    stash(0, nxt);
+    Stage R[DEPTH];
+    R[0] = fetch();
+    stash(0, R[0]);
+#pragma unroll
+    for (int u = 0; u < DEPTH; ++u) R[u] = fetch();      // R[u] <- step u + 1
     __syncthreads();
-    for (int step = 0; step < nsteps; ++step) {
-      nxt = fetch();                    // rows of step + 1, in flight while this step is multiplied
-      compute(step & 1);
-      stash((step + 1) & 1, nxt);       // zeros past the slice: written, never multiplied
-      __syncthreads();
+    // whole groups of DEPTH steps, no branch inside a group (the wait counts then stay exact); the up to DEPTH - 1
+    // extra steps multiply zeros
+    for (int step = 0; step < nsteps; step += DEPTH) {
+#pragma unroll
+      for (int u = 0; u < DEPTH; ++u) {
+        compute((step + u) & 1);
+        stash((step + u + 1) & 1, R[u]);                 // step + u + 1
+        R[u] = fetch();                                  // step + u + 1 + DEPTH
+        __syncthreads();
+      }
     }
   }
 
@@ -198,23 +218,57 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict_
 }
 
 struct TnPlan {
-  int tiles_n, tiles_k, slices, rows_per_slice;
+  int bn, tiles_n, tiles_k, slices, rows_per_slice;
 };
+// Tile height and slice count.  256-row tiles when the output is tall enough to give every CU work; the slice count is
+// the multiple of 8 (whole slices per XCD) that minimises a simple time model: rounds of resident workgroups x (steps
+// per slice + a fixed per-workgroup cost) plus the fp32 partial tiles written and read back.
 TnPlan tn_plan(int M, int N, int K) {
   TnPlan p;
-  p.tiles_n = (N + TN_BN - 1) / TN_BN;
+  p.bn = N >= 512 ? 256 : 128;
+  p.tiles_n = (N + p.bn - 1) / p.bn;
   p.tiles_k = (K + TN_BK - 1) / TN_BK;
   const int64_t tiles = (int64_t)p.tiles_n * p.tiles_k;
-  int64_t s = (TN_TARGET_WGS + tiles - 1) / tiles;
+  const int ncu = vitm_cu_count();
+  const int64_t slots = (int64_t)ncu * (p.bn == 128 ? 2 : 1);
   const int64_t smax = (M + TN_MIN_ROWS - 1) / TN_MIN_ROWS;
-  s = s > smax ? smax : s;
-  s = s < 1 ? 1 : (s > 64 ? 64 : s);
-  if (s > 1 && smax >= 8) s = (s + 7) / 8 * 8;   // one or more whole slices per XCD
-  int rps = (int)((M + s - 1) / s);
+  int best = 1;
+  if (smax >= 8) {
+    const double step_us = p.bn == 128 ? 0.75 : 1.35;                    // one 64-row step of one workgroup
+    const double part_us = 8.0 * (double)N * K / 4.0e6;                 // one slice's partial tile: write + read at 4 TB/s
+    double best_cost = 1e30;
+    for (int s = 8; s <= 64 && s <= smax; s += 8) {
+      const int64_t rounds = (tiles * s + slots - 1) / slots;
+      const int64_t steps = ((M + s - 1) / s + TN_BM - 1) / TN_BM;
+      const double cost = (double)rounds * ((double)steps * step_us + 4.0) + (double)s * part_us;
+      if (cost < best_cost) {
+        best_cost = cost;
+        best = s;
+      }
+    }
+  } else {
+    int64_t s = (slots + tiles - 1) / tiles;
+    s = s > smax ? smax : s;
+    best = (int)(s < 1 ? 1 : s);
+  }
+  int rps = (M + best - 1) / best;
   rps = (rps + TN_BM - 1) / TN_BM * TN_BM;
   p.rows_per_slice = rps;
-  p.slices = (int)s;                             // trailing slices may own no rows: they write zeros
+  p.slices = best;                               // trailing slices may own no rows: they write zeros
   return p;
+}
+
+template <int BN_>
+int tn_launch(const TnPlan& p, const bf16_t* a, int64_t lda, const bf16_t* b, int64_t ldb, float* dst, int64_t ldd,
+              int64_t slice_stride, float* csum, int M, int N, int K, hipStream_t st) {
+  constexpr int SMEM_ = 2 * TN_BM * ((BN_ * 2 + 64) + (TN_BK * 2 + 64));
+  auto kfn = gemm_tn_kernel<BN_, TN_DEPTH>;
+  VITM_LDS_OPTIN(kfn, SMEM_, "vitm_gemm_tn");
+  const dim3 grid((unsigned)(p.tiles_n * p.tiles_k * p.slices));
+  hipLaunchKernelGGL(kfn, grid, dim3(BN_ * 2), SMEM_, st, a, lda, b, ldb, dst, ldd, slice_stride, csum, M, N, K,
+                     p.rows_per_slice, p.tiles_k, p.slices);
+  VITM_CHECK_LAUNCH("vitm_gemm_tn");
+  return VITM_OK;
 }
 
 }  // namespace
@@ -235,25 +289,20 @@ extern "C" int vitm_gemm_tn(const void* a, int64_t lda, const void* b, int64_t l
   VITM_REQUIRE((((uintptr_t)a | (uintptr_t)b) & 15) == 0, "vitm_gemm_tn: operands must be 16-byte aligned");
   const TnPlan p = tn_plan(M, N, K);
   VITM_REQUIRE((int64_t)p.tiles_n * p.tiles_k * p.slices < (1ll << 31), "vitm_gemm_tn: grid too large for one launch");
-  VITM_REQUIRE(((int64_t)p.rows_per_slice + 3 * TN_BM) * (lda > ldb ? lda : ldb) * 2 < (1ll << 31),
+  VITM_REQUIRE(((int64_t)p.rows_per_slice + (2 * TN_DEPTH + 3) * TN_BM) * (lda > ldb ? lda : ldb) * 2 < (1ll << 31),
                "vitm_gemm_tn: a slice of rows must stay below 2 GiB");
   const int64_t need = p.slices > 1 ? (int64_t)p.slices * ((int64_t)N * K + N) : 0;
   VITM_REQUIRE(need == 0 || (workspace && workspace_floats >= need),
                "vitm_gemm_tn: workspace of %lld floats needed (vitm_gemm_tn_workspace_floats)", (long long)need);
   hipStream_t st = (hipStream_t)stream;
-  auto kfn = gemm_tn_kernel;
-  VITM_LDS_OPTIN(kfn, 4 * TN_TILE, "vitm_gemm_tn");
-  const dim3 grid((unsigned)(p.tiles_n * p.tiles_k * p.slices));
-  if (p.slices == 1) {
-    hipLaunchKernelGGL(kfn, grid, dim3(256), 4 * TN_TILE, st, (const bf16_t*)a, lda, (const bf16_t*)b, ldb, out, ldo,
-                       (int64_t)0, colsum_out, M, N, K, p.rows_per_slice, p.tiles_k, p.slices);
-    VITM_CHECK_LAUNCH("vitm_gemm_tn");
-    return VITM_OK;
-  }
-  hipLaunchKernelGGL(kfn, grid, dim3(256), 4 * TN_TILE, st, (const bf16_t*)a, lda, (const bf16_t*)b, ldb, workspace,
-                     (int64_t)K, (int64_t)N * K, colsum_out ? workspace + (int64_t)p.slices * N * K : nullptr, M, N, K,
-                     p.rows_per_slice, p.tiles_k, p.slices);
-  VITM_CHECK_LAUNCH("vitm_gemm_tn");
+  const bf16_t *ap = (const bf16_t*)a, *bp = (const bf16_t*)b;
+  const bool direct = p.slices == 1;
+  float* dst = direct ? out : workspace;
+  const int64_t ldd = direct ? ldo : (int64_t)K, sstride = direct ? 0 : (int64_t)N * K;
+  float* cs = !colsum_out ? nullptr : (direct ? colsum_out : workspace + (int64_t)p.slices * N * K);
+  const int rc = p.bn == 256 ? tn_launch<256>(p, ap, lda, bp, ldb, dst, ldd, sstride, cs, M, N, K, st)
+                             : tn_launch<128>(p, ap, lda, bp, ldb, dst, ldd, sstride, cs, M, N, K, st);
+  if (rc != VITM_OK || direct) return rc;
   const int64_t total = (int64_t)N * K;
   int64_t g = (total + 255) / 256;
   g = g > 4096 ? 4096 : g;
