@@ -8,14 +8,13 @@
 //
 // The output is small (a weight matrix) and the reduction is long (every token of the batch), so the reduction is split
 // over workgroup slices: each slice writes its own fp32 partial tile and a second kernel adds the slices in a
-// fixed order (deterministic; no atomics).  Workgroup = 8 (or 4) waves, 256 (or 128) x 128 output tile, 64 x 64 per
-// wave as 2 x 2 v_mfma_f32_32x32x16_bf16 tiles; the global loads of the next 64-row step are in flight while the current one is
+// fixed order (deterministic; no atomics).  Workgroup = 8 waves on a 256 x 256 output tile (128 x 64 per wave as 4 x 2
+// v_mfma_f32_32x32x16_bf16 tiles) or 4 waves on 128 x 128; the global loads of the next 64-row step are in flight while the current one is
 // multiplied (register staging, two LDS buffers, one barrier per step).
 #include "common.h"
 
 namespace {
 
-constexpr int TN_BK = 128;            // output columns (columns of b) per workgroup
 constexpr int TN_BM = 64;             // reduction rows per step
 // LDS row strides are (tile row bytes) + 64, i.e. 64 mod 256: the four rows a transposing read touches per half-wave
 // (4 x 64 bytes) then fall in four different quarters of the 64 banks (SQ_LDS_BANK_CONFLICT = 0)
@@ -40,28 +39,37 @@ __device__ __forceinline__ bf16x8_t tn_frag(const char* a0) {
   return __builtin_bit_cast(bf16x8_t, t);
 }
 
-// BN_ = output rows per workgroup: 128 (4 waves as 2 x 2, two workgroups per CU) or 256 (8 waves as 4 x 2, one per CU:
-// a quarter less operand traffic per MAC, the b tile being shared by twice as many rows).  Each wave owns 64 x 64.
-template <int BN_, int DEPTH>
-__global__ __launch_bounds__(BN_ * 2, BN_ == 128 ? 2 : 1) void gemm_tn_kernel(
+// BN_ x BK_ = output tile of a workgroup, FI = 32-row fragments per wave (a wave owns 32 FI x 64 of the tile):
+//   128 x 128, FI 2: 4 waves as 2 x 2, two workgroups per CU (small outputs)
+//   256 x 256, FI 4: 8 waves as 2 x 4, one workgroup per CU -- half the operand bytes per MAC.  Operands reach a CU at
+//                    15-20 B/clk whatever the tile, prefetch depth or number of resident workgroups (measured), so the
+//                    MACs per operand byte of the tile set the speed: 64 -> ~650 TFLOP/s, 128 -> ~1 PFLOP/s.
+template <int BN_, int BK_, int FI, int DEPTH>
+__global__ __launch_bounds__((BN_ / (32 * FI)) * (BK_ / 64) * 64, BN_ == 128 ? 2 : 1) void gemm_tn_kernel(
     const bf16_t* __restrict__ a, int64_t lda, const bf16_t* __restrict__ b, int64_t ldb, float* __restrict__ dst,
     int64_t ldd, int64_t slice_stride, float* __restrict__ csum, int M, int N, int K, int rows_per_slice, int tiles_k,
-    int nslices) {
-  constexpr int NT_ = BN_ * 2;                       // threads
-  constexpr int RSA = BN_ * 2 + 64, RSB = TN_BK * 2 + 64;   // LDS row strides (bytes): 64 mod 256, see TN_RS
+    int nslices, int npairs) {
+  constexpr int WK_ = BK_ / 64;                      // waves along the output columns
+  constexpr int NT_ = (BN_ / (32 * FI)) * WK_ * 64;  // threads
+  constexpr int RSA = BN_ * 2 + 64, RSB = BK_ * 2 + 64;     // LDS row strides (bytes): 64 mod 256
   constexpr int TILE_A = TN_BM * RSA, TILE_B = TN_BM * RSB, STAGE = TILE_A + TILE_B;
-  constexpr int CA = BN_ / 8, CB = TN_BK / 8;        // 16-byte chunks per tile row
+  constexpr int CA = BN_ / 8, CB = BK_ / 8;          // 16-byte chunks per tile row
   constexpr int RPA = NT_ / CA, RPB = NT_ / CB;      // rows covered by one pass of the workgroup
   constexpr int JA = TN_BM / RPA, JB = TN_BM / RPB;  // passes (loads per thread) per step
   extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 buffers][a tile, b tile]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, hh = lane >> 5;
-  // Workgroups are dealt to the 8 XCDs round-robin by their linear index.  The slice is the fast index, so (with a
-  // slice count that is a multiple of 8) all tiles of one slice run on one XCD and share its L2: each 64-row step of
-  // the slice's rows is fetched from HBM once per XCD instead of once per output tile.
-  const int slice = blockIdx.x % nslices, tile = blockIdx.x / nslices;
+  // Workgroups are dealt to the 8 XCDs round-robin by their linear index.  XCD x takes the x-th eighth of the
+  // (slice, tile) pairs in slice-major order, so the tiles of one slice run on one XCD (two at a boundary) and share
+  // its L2: each 64-row step of a slice's rows is fetched from HBM about once instead of once per output tile, for
+  // any slice count.
+  const int per_xcd = (npairs + 7) >> 3;
+  const int pair = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  if ((int)(blockIdx.x >> 3) >= per_xcd || pair >= npairs) return;   // block-uniform: the padding of the last eighth
+  const int tiles = npairs / nslices;
+  const int slice = pair / tiles, tile = pair - slice * tiles;
   const int tn = tile / tiles_k, tk = tile - tn * tiles_k;
-  const int n0 = tn * BN_, k0 = tk * TN_BK;
+  const int n0 = tn * BN_, k0 = tk * BK_;
   const int m_begin = slice * rows_per_slice;
   int m_end = m_begin + rows_per_slice;
   m_end = m_end < M ? m_end : M;
@@ -107,9 +115,9 @@ __global__ __launch_bounds__(BN_ * 2, BN_ == 128 ? 2 : 1) void gemm_tn_kernel(
     for (int j = 0; j < JB; ++j) *(u32x4_t*)(base + soffb + j * RPB * RSB) = st.b[j];
   };
 
-  f32x16_t acc[2][2];
+  f32x16_t acc[FI][2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < FI; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -117,11 +125,12 @@ __global__ __launch_bounds__(BN_ * 2, BN_ == 128 ? 2 : 1) void gemm_tn_kernel(
 
   const int g16 = lane >> 4, li = lane & 15;
   const int trow = 4 * hh + (li >> 2), tcol = (16 * (g16 & 1) + 4 * (li & 3)) * 2;
-  const int wn = wave >> 1, wk = wave & 1;
-  const int a_off = trow * RSA + tcol + (64 * wn) * 2, b_off = TILE_A + trow * RSB + tcol + (64 * wk) * 2;
+  const int wn = wave / WK_, wk = wave % WK_;
+  const int a_off = trow * RSA + tcol + (32 * FI * wn) * 2, b_off = TILE_A + trow * RSB + tcol + (64 * wk) * 2;
   // column sums of a (the bias gradient) ride along on the workgroups of the first column tile: one more product
-  // per a fragment, against a fragment of ones -- every column of that accumulator is sum_m a[m, n]
-  const bool want_csum = csum != nullptr && tk == 0 && wk == 0;   // wave-uniform
+  // per a fragment, against a fragment of ones -- every column of that accumulator is sum_m a[m, n].  The waves of a
+  // wave row share the duty, two fragments each (wave column wk takes fragments 2 wk, 2 wk + 1).
+  const bool want_csum = csum != nullptr && tk == 0 && wk < FI / 2;   // wave-uniform
   f32x16_t cacc[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -137,15 +146,23 @@ __global__ __launch_bounds__(BN_ * 2, BN_ == 128 ? 2 : 1) void gemm_tn_kernel(
     for (int s2 = 0; s2 < TN_BM / 16; ++s2) {
       const char* ta = base + 16 * s2 * RSA + a_off;
       const char* tb = base + 16 * s2 * RSB + b_off;
-      const bf16x8_t a0 = tn_frag<RSA>(ta), a1 = tn_frag<RSA>(ta + 64);
+      bf16x8_t af[FI];
+#pragma unroll
+      for (int i = 0; i < FI; ++i) af[i] = tn_frag<RSA>(ta + 64 * i);
       const bf16x8_t b0 = tn_frag<RSB>(tb), b1 = tn_frag<RSB>(tb + 64);
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < FI; ++i) {
+        acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], b0, acc[i][0], 0, 0, 0);
+        acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], b1, acc[i][1], 0, 0, 0);
+      }
       if (want_csum) {
-        cacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, ones, cacc[0], 0, 0, 0);
-        cacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, ones, cacc[1], 0, 0, 0);
+        if (FI == 2 || wk == 0) {
+          cacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], ones, cacc[0], 0, 0, 0);
+          cacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], ones, cacc[1], 0, 0, 0);
+        } else {
+          cacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[FI - 2], ones, cacc[0], 0, 0, 0);
+          cacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[FI - 1], ones, cacc[1], 0, 0, 0);
+        }
       }
     }
   };
@@ -179,20 +196,20 @@ __global__ __launch_bounds__(BN_ * 2, BN_ == 128 ? 2 : 1) void gemm_tn_kernel(
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        const int n = n0 + 64 * wn + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * hh;
+        const int n = n0 + 32 * FI * wn + 32 * (2 * wk + i) + (e & 3) + 8 * (e >> 2) + 4 * hh;
         if (n < N) co[n] = cacc[i][e];
       }
   }
   float* out = dst + (int64_t)slice * slice_stride;
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < FI; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int kc = k0 + 64 * wk + 32 * j + r;
       if (kc >= K) continue;
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        const int n = n0 + 64 * wn + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * hh;
+        const int n = n0 + 32 * FI * wn + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * hh;
         if (n < N) out[(int64_t)n * ldd + kc] = acc[i][j][e];
       }
     }
@@ -218,38 +235,34 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict_
 }
 
 struct TnPlan {
-  int bn, tiles_n, tiles_k, slices, rows_per_slice;
+  int bn, bk, tiles_n, tiles_k, slices, rows_per_slice;   // bn = bk = 128 or 256
 };
-// Tile height and slice count.  256-row tiles when the output is tall enough to give every CU work; the slice count is
-// the multiple of 8 (whole slices per XCD) that minimises a simple time model: rounds of resident workgroups x (steps
+// Tile size and slice count.  256 x 256 tiles when the output is large enough; the slice count minimises a simple time
+// model: rounds of resident workgroups x (steps
 // per slice + a fixed per-workgroup cost) plus the fp32 partial tiles written and read back.
 TnPlan tn_plan(int M, int N, int K) {
   TnPlan p;
-  p.bn = N >= 512 ? 256 : 128;
+  p.bn = p.bk = (N >= 512 && K >= 256) ? 256 : 128;
   p.tiles_n = (N + p.bn - 1) / p.bn;
-  p.tiles_k = (K + TN_BK - 1) / TN_BK;
+  p.tiles_k = (K + p.bk - 1) / p.bk;
   const int64_t tiles = (int64_t)p.tiles_n * p.tiles_k;
   const int ncu = vitm_cu_count();
   const int64_t slots = (int64_t)ncu * (p.bn == 128 ? 2 : 1);
   const int64_t smax = (M + TN_MIN_ROWS - 1) / TN_MIN_ROWS;
   int best = 1;
-  if (smax >= 8) {
-    const double step_us = p.bn == 128 ? 0.75 : 1.35;                    // one 64-row step of one workgroup
+  {
+    const double step_us = p.bn == 128 ? 0.75 : 2.1;                     // one 64-row step of one workgroup
     const double part_us = 8.0 * (double)N * K / 4.0e6;                 // one slice's partial tile: write + read at 4 TB/s
     double best_cost = 1e30;
-    for (int s = 8; s <= 64 && s <= smax; s += 8) {
+    for (int s = 1; s <= 64 && s <= smax; ++s) {
       const int64_t rounds = (tiles * s + slots - 1) / slots;
       const int64_t steps = ((M + s - 1) / s + TN_BM - 1) / TN_BM;
-      const double cost = (double)rounds * ((double)steps * step_us + 4.0) + (double)s * part_us;
+      const double cost = (double)rounds * ((double)steps * step_us + 4.0) + (s > 1 ? (double)s * part_us : 0.0);
       if (cost < best_cost) {
         best_cost = cost;
         best = s;
       }
     }
-  } else {
-    int64_t s = (slots + tiles - 1) / tiles;
-    s = s > smax ? smax : s;
-    best = (int)(s < 1 ? 1 : s);
   }
   int rps = (M + best - 1) / best;
   rps = (rps + TN_BM - 1) / TN_BM * TN_BM;
@@ -258,15 +271,17 @@ TnPlan tn_plan(int M, int N, int K) {
   return p;
 }
 
-template <int BN_>
+template <int BN_, int BK_, int FI>
 int tn_launch(const TnPlan& p, const bf16_t* a, int64_t lda, const bf16_t* b, int64_t ldb, float* dst, int64_t ldd,
               int64_t slice_stride, float* csum, int M, int N, int K, hipStream_t st) {
-  constexpr int SMEM_ = 2 * TN_BM * ((BN_ * 2 + 64) + (TN_BK * 2 + 64));
-  auto kfn = gemm_tn_kernel<BN_, TN_DEPTH>;
+  constexpr int SMEM_ = 2 * TN_BM * ((BN_ * 2 + 64) + (BK_ * 2 + 64));
+  constexpr int DEPTH_ = BN_ == 256 ? 1 : TN_DEPTH;   // the 256 x 256 tile's accumulators leave registers for one step
+  auto kfn = gemm_tn_kernel<BN_, BK_, FI, DEPTH_>;
   VITM_LDS_OPTIN(kfn, SMEM_, "vitm_gemm_tn");
-  const dim3 grid((unsigned)(p.tiles_n * p.tiles_k * p.slices));
-  hipLaunchKernelGGL(kfn, grid, dim3(BN_ * 2), SMEM_, st, a, lda, b, ldb, dst, ldd, slice_stride, csum, M, N, K,
-                     p.rows_per_slice, p.tiles_k, p.slices);
+  const int npairs = p.tiles_n * p.tiles_k * p.slices;
+  const dim3 grid((unsigned)(8 * ((npairs + 7) / 8)));
+  hipLaunchKernelGGL(kfn, grid, dim3((BN_ / (32 * FI)) * (BK_ / 64) * 64), SMEM_, st, a, lda, b, ldb, dst, ldd, slice_stride, csum, M, N, K,
+                     p.rows_per_slice, p.tiles_k, p.slices, npairs);
   VITM_CHECK_LAUNCH("vitm_gemm_tn");
   return VITM_OK;
 }
@@ -300,8 +315,8 @@ extern "C" int vitm_gemm_tn(const void* a, int64_t lda, const void* b, int64_t l
   float* dst = direct ? out : workspace;
   const int64_t ldd = direct ? ldo : (int64_t)K, sstride = direct ? 0 : (int64_t)N * K;
   float* cs = !colsum_out ? nullptr : (direct ? colsum_out : workspace + (int64_t)p.slices * N * K);
-  const int rc = p.bn == 256 ? tn_launch<256>(p, ap, lda, bp, ldb, dst, ldd, sstride, cs, M, N, K, st)
-                             : tn_launch<128>(p, ap, lda, bp, ldb, dst, ldd, sstride, cs, M, N, K, st);
+  const int rc = p.bn == 256 ? tn_launch<256, 256, 4>(p, ap, lda, bp, ldb, dst, ldd, sstride, cs, M, N, K, st)
+                             : tn_launch<128, 128, 2>(p, ap, lda, bp, ldb, dst, ldd, sstride, cs, M, N, K, st);
   if (rc != VITM_OK || direct) return rc;
   const int64_t total = (int64_t)N * K;
   int64_t g = (total + 255) / 256;
