@@ -137,7 +137,7 @@ def _block_forward(blk: Block, x: torch.Tensor, B: int, N: int) -> (torch.Tensor
     T.residual_scale(x, z1, _ops.f32vec(blk.ls1.gamma), x1, M, D)
     n2 = x1
     if ln2 is not None:
-        n2 = n1 if ln1 is not None else _buf(M, D, dev, cd)       # reuse the scratch
+        n2 = _buf(M, D, dev, cd)
         _ops.layernorm(x1, n2, M, D, ln2[0], ln2[1], ln2[2])
     pre = _buf(M, hid, dev, cd)
     p1 = _pk(mlp.linear_layer1.weight, mlp.linear_layer1.bias, cd)
@@ -148,7 +148,7 @@ def _block_forward(blk: Block, x: torch.Tensor, B: int, N: int) -> (torch.Tensor
     _ops.gemm(h, _pk(mlp.linear_layer2.weight, mlp.linear_layer2.bias, cd), z2, _ops.EPI_BIAS, M)
     x2 = _buf(M, D, dev, cd)
     T.residual_scale(x1, z2, _ops.f32vec(blk.ls2.gamma), x2, M, D)
-    s.update(z1=z1, x1=x1, pre=pre, h=h, z2=z2)
+    s.update(n1=n1, n2=n2, z1=z1, x1=x1, pre=pre, h=h, z2=z2)   # HBM is plentiful: nothing is recomputed in the backward
     return x2, s
 
 
@@ -245,11 +245,7 @@ def _block_backward(G: _Grads, blk: Block, s: dict, dx2: torch.Tensor, B: int, N
     dh = _linear_backward(G, mlp.linear_layer2, dz2, s["h"], M)
     dpre = dh                                             # in place: element-wise
     T.gelu_bwd(s["pre"], dh, dpre, M, hid)
-    n2 = s["x1"]
-    if ln2 is not None:
-        n2 = _buf(M, D, dev, cd)
-        _ops.layernorm(s["x1"], n2, M, D, ln2[0], ln2[1], ln2[2])
-    dn2 = _linear_backward(G, mlp.linear_layer1, dpre, n2, M)
+    dn2 = _linear_backward(G, mlp.linear_layer1, dpre, s["n2"], M)
     dx1 = _buf(M, D, dev, cd)
     if ln2 is not None:
         T.layernorm_bwd(s["x1"], dn2, ln2[0], ln2[2], M, D, dx1, dx_add=dx2, dw_out=G.buf(ln2[3]), db_out=G.buf(ln2[4]))
@@ -263,11 +259,7 @@ def _block_backward(G: _Grads, blk: Block, s: dict, dx2: torch.Tensor, B: int, N
     d_o = _linear_backward(G, attn.proj, dz1, s["o"], M)
     dqkv = torch.empty((M, 3 * D), dtype=cd, device=dev)
     _attention_backward(G, attn, s, d_o, dqkv, B, N, "Attention")
-    n1 = s["x"]
-    if ln1 is not None:
-        n1 = n2 if ln2 is not None else _buf(M, D, dev, cd)
-        _ops.layernorm(s["x"], n1, M, D, ln1[0], ln1[1], ln1[2])
-    dn1 = _linear_backward(G, attn.qkv, dqkv, n1, M)
+    dn1 = _linear_backward(G, attn.qkv, dqkv, s["n1"], M)
     dx = _buf(M, D, dev, cd)
     if ln1 is not None:
         T.layernorm_bwd(s["x"], dn1, ln1[0], ln1[2], M, D, dx, dx_add=dx1, dw_out=G.buf(ln1[3]), db_out=G.buf(ln1[4]))
