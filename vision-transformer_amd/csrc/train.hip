@@ -535,34 +535,36 @@ __global__ __launch_bounds__(256) void residual_scale_kernel(const T* __restrict
   }
 }
 
-// ---- softmax cross-entropy, mean over the batch (one workgroup: the batch of logits is small) ------------------------
-__global__ __launch_bounds__(256) void cross_entropy_kernel(const float* __restrict__ logits, int64_t ld,
-                                                            const int64_t* __restrict__ labels, int B, int C,
-                                                            float* __restrict__ loss, float* __restrict__ dlogits, int64_t lddl) {
-  __shared__ float part[4];
+// ---- softmax cross-entropy, mean over the batch: one wave per row (rows spread over the chip), then one wave adds
+// the per-row losses in a fixed order ------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cross_entropy_rows_kernel(const float* __restrict__ logits, int64_t ld,
+                                                                 const int64_t* __restrict__ labels, int B, int C,
+                                                                 float* __restrict__ row_loss,
+                                                                 float* __restrict__ dlogits, int64_t lddl) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = blockIdx.x * 4 + wave;
+  if (r >= B) return;   // wave-uniform
   const float inv_b = 1.0f / (float)B;
-  float acc = 0.f;
-  for (int r = wave; r < B; r += 4) {
-    const float* row = logits + (int64_t)r * ld;
-    float mx = -3.0e38f;
-    for (int c = lane; c < C; c += 64) mx = fmaxf(mx, row[c]);
+  const float* row = logits + (int64_t)r * ld;
+  float mx = -3.0e38f;
+  for (int c = lane; c < C; c += 64) mx = fmaxf(mx, row[c]);
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
-    float s = 0.f;
-    for (int c = lane; c < C; c += 64) s += __expf(row[c] - mx);
-    s = wave_sum(s);
-    const float lse = mx + __logf(s);
-    const int y = (int)labels[r];
-    if (lane == 0) acc += lse - row[y];
-    if (dlogits) {
-      const float is = 1.0f / s;
-      for (int c = lane; c < C; c += 64) dlogits[(int64_t)r * lddl + c] = (__expf(row[c] - mx) * is - (c == y ? 1.f : 0.f)) * inv_b;
-    }
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  float s = 0.f;
+  for (int c = lane; c < C; c += 64) s += __expf(row[c] - mx);
+  s = wave_sum(s);
+  const int y = (int)labels[r];
+  if (lane == 0) row_loss[r] = mx + __logf(s) - row[y];
+  if (dlogits) {
+    const float is = 1.0f / s;
+    for (int c = lane; c < C; c += 64) dlogits[(int64_t)r * lddl + c] = (__expf(row[c] - mx) * is - (c == y ? 1.f : 0.f)) * inv_b;
   }
-  if (lane == 0) part[wave] = acc;
-  __syncthreads();
-  if (threadIdx.x == 0) loss[0] = ((part[0] + part[1]) + (part[2] + part[3])) * inv_b;
+}
+__global__ __launch_bounds__(64) void cross_entropy_mean_kernel(const float* __restrict__ row_loss, int B, float* __restrict__ loss) {
+  float s = 0.f;
+  for (int i = threadIdx.x; i < B; i += 64) s += row_loss[i];
+  s = wave_sum(s);
+  if (threadIdx.x == 0) loss[0] = s / (float)B;
 }
 
 // ---- gradient norm, clip coefficient, in-place scale ---------------------------------------------------------------
@@ -731,10 +733,12 @@ extern "C" int vitm_residual_scale(const void* resid, int64_t ldr, const void* z
 }
 
 extern "C" int vitm_cross_entropy_f32(const float* logits, int64_t ld, const int64_t* labels, int B, int C, float* loss,
-                                      float* dlogits, int64_t lddl, vitm_stream_t stream) {
-  VITM_REQUIRE(logits && labels && loss, "vitm_cross_entropy_f32: null pointer");
+                                      float* dlogits, int64_t lddl, float* row_loss, vitm_stream_t stream) {
+  VITM_REQUIRE(logits && labels && loss && row_loss, "vitm_cross_entropy_f32: null pointer");
   VITM_REQUIRE(B > 0 && C > 0 && ld >= C && (!dlogits || lddl >= C), "vitm_cross_entropy_f32: bad shape");
-  hipLaunchKernelGGL(cross_entropy_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, logits, ld, labels, B, C, loss, dlogits, lddl);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(cross_entropy_rows_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, st, logits, ld, labels, B, C, row_loss, dlogits, lddl);
+  hipLaunchKernelGGL(cross_entropy_mean_kernel, dim3(1), dim3(64), 0, st, (const float*)row_loss, B, loss);
   VITM_CHECK_LAUNCH("vitm_cross_entropy_f32");
   return VITM_OK;
 }

@@ -76,7 +76,8 @@ SIGNATURES = {
     "vitm_qk_norm_bwd": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p, c_float, c_void_p,
                                  c_float, c_void_p, c_int, c_void_p]),
     "vitm_gelu_bwd": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
-    "vitm_cross_entropy_f32": (c_int, [c_void_p, c_int64, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int64, c_void_p]),
+    "vitm_cross_entropy_f32": (c_int, [c_void_p, c_int64, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int64, c_void_p,
+                                       c_void_p]),
     "vitm_grad_clip_f32": (c_int, [c_void_p, c_int64, c_float, c_void_p, c_void_p, c_void_p]),
     "vitm_grad_clip_scratch_floats": (c_int, []),
     "vitm_adamw_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float, c_float,

@@ -12,6 +12,7 @@ from . import _lib
 from ._ops import _p, _dt, _stream, round_up, k_multiple, pack_linear, gemm, to_f32, to_bf16, EPI_BIAS, PackedLinear
 
 COLSUM_CHUNKS = 64
+COLSUM_WORKGROUPS = 1024
 LN_BWD_BLOCKS = 1024
 F32 = torch.float32
 
@@ -89,7 +90,8 @@ def colsum(a: torch.Tensor, M: int, D: int, b: Optional[torch.Tensor] = None, ou
     if out is None:
         out = torch.empty(D, dtype=F32, device=a.device)
     dt = _rm(a) if b is None else _rm(a, b)
-    nch = min(COLSUM_CHUNKS, M // 16) if M >= 32 else 1      # short inputs: one stage
+    # row chunks: enough workgroups (one per 256 columns x chunk) to fill the chip, at least 16 rows each
+    nch = min(max(COLSUM_CHUNKS, COLSUM_WORKGROUPS // ((D + 255) // 256)), 512, M // 16) if M >= 32 else 1
     ldb = 0 if b is None else b.stride(0)
     if nch > 1:
         part = torch.empty((nch, D), dtype=F32, device=a.device)
@@ -145,10 +147,11 @@ def cross_entropy(logits, labels, want_grad=True):
     """(loss scalar tensor, dlogits or None): mean softmax cross-entropy over the batch."""
     B, C = logits.shape
     loss = torch.empty(1, dtype=torch.float32, device=logits.device)
+    row_loss = torch.empty(B, dtype=torch.float32, device=logits.device)
     dl = torch.empty((B, C), dtype=torch.float32, device=logits.device) if want_grad else None
     lab = labels.to(torch.int64).contiguous()
     _lib.check(_lib.load().vitm_cross_entropy_f32(_p(_f32(logits)), logits.stride(0), _p(lab), B, C, _p(loss), _p(dl),
-                                                  C, _stream()), "vitm_cross_entropy_f32")
+                                                  C, _p(row_loss), _stream()), "vitm_cross_entropy_f32")
     return loss, dl
 
 
