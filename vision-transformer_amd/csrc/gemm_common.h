@@ -19,6 +19,7 @@ struct GemmArgs {
   int64_t ldr;
   int M, N, K, tilesM, tilesN, row_group;
   int ncu, share, S;   // big-tile kernel: persistent workgroups, leftover tiles shared (0/1) by S workgroups each
+  int band;            // big-tile kernel: N-tiles per column band of the tile order (tilesN: plain row-major)
   // im2col source (patch embedding)
   const void* img;
   int C, H, Wd, ph, pw, gw, npatch, kreal, vec;

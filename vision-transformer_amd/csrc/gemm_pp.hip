@@ -46,6 +46,7 @@
 // consecutive columns per lane, a DPP row rotate pairs rows r and r+8, and each store instruction then writes 8 rows
 // x 128 contiguous bytes (whole cache lines: 16 rows x 64 bytes measured 3x slower to drain).  Stores are never
 // waited for inside the tile that issued them.
+#include <stdlib.h>
 #include "gemm_common.h"
 
 #ifndef PP_ABLATE
@@ -184,6 +185,17 @@ __global__ __launch_bounds__(NT, 2) void gemm_pp_kernel(const GemmArgs p) {
   const int full = SLICE ? 0 : d.full;
   const int wpx = d.wpx;
   auto tile_of = [&](int it) { return it < full ? d.base + lg + it * wpx : lo_tile; };
+  // Tile order: column bands of p.band N-tiles, row-major inside a band (the last band may be narrower).  The weight
+  // rows of a band (band x 256 x K) fit an XCD's L2, so they are fetched once per XCD and band instead of once per
+  // A row panel; the A panels are read once per band.
+  auto tile_mn = [&](int w, int& mt, int& nt) {
+    const int per_band = p.tilesM * p.band;
+    const int b = w / per_band, r = w - b * per_band;
+    int bw = p.tilesN - b * p.band;
+    bw = bw < p.band ? bw : p.band;
+    mt = r / bw;
+    nt = b * p.band + (r - mt * bw);
+  };
   const int nk = p.K / BK;
 
   // ---- DMA: this wave moves rows 32w..32w+31 of every A tile and of every W tile, as 4 + 4 pieces of 8 rows x
@@ -202,8 +214,9 @@ __global__ __launch_bounds__(NT, 2) void gemm_pp_kernel(const GemmArgs p) {
     a_hi = a_hi < a_lo ? a_lo : a_hi;
   }
   auto set_a = [&](int it) {
-    const int w = tile_of(it);
-    const int am0 = (w / p.tilesN) * BM;
+    int mt, nt;
+    tile_mn(tile_of(it), mt, nt);
+    const int am0 = mt * BM;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       int am = am0 + (4 * wave + q) * 8 + lr;
@@ -212,8 +225,9 @@ __global__ __launch_bounds__(NT, 2) void gemm_pp_kernel(const GemmArgs p) {
     }
   };
   auto set_w = [&](int it) {
-    const int w = tile_of(it);
-    const int wn0 = (w % p.tilesN) * BN;
+    int mt, nt;
+    tile_mn(tile_of(it), mt, nt);
+    const int wn0 = nt * BN;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       int wn = wn0 + (4 * wave + q) * 8 + lr;
@@ -304,8 +318,10 @@ __global__ __launch_bounds__(NT, 2) void gemm_pp_kernel(const GemmArgs p) {
 
   for (int it = 0; it < ntl; ++it) {
     const int wgid = tile_of(it);
-    const int m0 = (wgid / p.tilesN) * BM;
-    const int n0 = (wgid % p.tilesN) * BN;
+    int mt_, nt_;
+    tile_mn(wgid, mt_, nt_);
+    const int m0 = mt_ * BM;
+    const int n0 = nt_ * BN;
 #pragma unroll
     for (int i = 0; i < NBLK; ++i)
 #pragma unroll
@@ -486,6 +502,16 @@ int launch(const GemmArgs& a, hipStream_t st) {
   GemmArgs b = a;
   b.tilesN = (a.N + BN - 1) / BN;
   b.tilesM = (a.M + BM - 1) / BM;
+  {
+    // weight bytes of one N-tile: BN x K x 2; a band is what stays resident in a 4 MiB L2 next to the A stream
+    static const int64_t band_bytes = [] { const char* e = getenv("VITM_PP_BAND_KB"); return (int64_t)(e ? atoi(e) : 2560) * 1024; }();
+    int64_t band = band_bytes / ((int64_t)BN * a.K * 2);
+    band = band < 1 ? 1 : band;
+    // even bands, and none when a single band would hold more than half of the tiles anyway
+    const int64_t nb = (b.tilesN + band - 1) / band;
+    band = (b.tilesN + nb - 1) / nb;
+    b.band = (band_bytes > 0 && a.K <= 1024 && nb > 1) ? (int)band : b.tilesN;
+  }
   const int ncu = vitm_cu_count();
   const int64_t tiles = (int64_t)b.tilesM * b.tilesN;
   const int grid = (int)(tiles < ncu ? tiles : ncu);   // one persistent workgroup per CU
