@@ -352,3 +352,30 @@ def test_training_parallel_blocks(monkeypatch, bf16):
     for _ in range(3):
         l1 = tr.step(x.cuda(), y.cuda()).item()
     assert l1 < l0
+
+
+def test_checkpoint_round_trip_of_a_trainer(tmp_path):
+    """The end-of-training dictionary (train.py:245-249) written from a Trainer whose parameters and AdamW moments
+    live in flat buffers: loads with weights_only=True into a fresh model / optimizer, file holds each buffer once."""
+    from vitm_amd import training
+    from vitm_amd.utils.checkpoint import load_checkpoint, save_checkpoint
+    cfg = W.CONFIGS["tiny2"]
+    a = _model(cfg, 21)
+    opt_a, sched_a = training.reference_optimizer_and_scheduler(a, 1000)
+    tr_a = training.Trainer(a, opt_a, sched_a, max_norm=1.0)
+    for step in range(2):
+        tr_a.step(*_batch(cfg, 4, 300 + step))
+    path = str(tmp_path / "ckpt.pt")
+    save_checkpoint(a, path, opt_a, sched_a)
+    nbytes = sum(p.numel() for p in a.parameters()) * 4
+    assert os.path.getsize(path) < 3.5 * nbytes, "parameters + two moments, each stored once"
+    b = _model(cfg, 1)
+    opt_b, sched_b = training.reference_optimizer_and_scheduler(b, 1000)
+    tr_b = training.Trainer(b, opt_b, sched_b, max_norm=1.0)
+    load_checkpoint(b, path, opt_b, sched_b)
+    assert tr_b.params.intact(), "load_state_dict copies into the flat views"
+    x, y = _batch(cfg, 4, 302)
+    la, lb = tr_a.step(x, y), tr_b.step(x, y)
+    assert la.item() == lb.item()
+    for (k, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):
+        assert torch.equal(pa, pb), k
