@@ -106,3 +106,54 @@ def test_flat_gradient_allreduce_two_ranks():
     for p in procs:
         p.join(timeout=60)
     assert res == [(0, True), (1, True)]
+
+
+def _reducer_worker(rank, world, port, q):
+    import os
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from vitm_amd.training import FlatGradients, GradientReducer
+        torch.manual_seed(0)
+        layers = [torch.nn.Linear(40, 40) for _ in range(5)]
+        net = torch.nn.Sequential(*layers)
+        fg = FlatGradients(net.parameters())
+        red = GradientReducer(fg, None, bucket_bytes=2 * 40 * 40 * 4)     # about two layers per bucket
+        assert red.active and not red.avg
+        for i, p in enumerate(net.parameters()):
+            p.grad.fill_(float(rank + 1) * (i + 1))
+        fired = []
+        for layer in reversed(layers):                # the order a backward pass finishes them in
+            red.ready(list(layer.parameters()))
+            fired.append(len(red.works))
+        nworks = len(red.works)
+        red.finish()
+        want = sum(r + 1 for r in range(world)) / world
+        ok = all(torch.allclose(p.grad, torch.full_like(p, want * (i + 1))) for i, p in enumerate(net.parameters()))
+        # buckets went out while "the backward" was still running, and the alignment gaps stayed zero
+        mask = torch.ones_like(fg.flat, dtype=torch.bool)
+        for p, off in zip(fg.params, fg.offsets):
+            mask[off:off + p.numel()] = False
+        ok = ok and 1 <= nworks < len(layers) and fired[0] == 0 and float(fg.flat[mask].abs().sum()) == 0.0
+        ok = ok and len(red.works) == 0               # ready for the next step
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bucketed_gradient_allreduce_two_ranks():
+    """The overlapped data-parallel exchange: contiguous slices of the flat gradient buffer go out in buckets as the
+    backward reaches them (last layer first); rehearsed over gloo."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000) + 11
+    procs = [ctx.Process(target=_reducer_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    assert res == [(0, True), (1, True)]

@@ -347,9 +347,10 @@ def _add(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, M: int, D: int) ->
     T.residual_scale(a, b, ones, out, M, D)
 
 
-def backward_train(model, S: dict, dlogits: torch.Tensor, sink=None) -> Dict[nn.Parameter, torch.Tensor]:
+def backward_train(model, S: dict, dlogits: torch.Tensor, sink=None, on_ready=None) -> Dict[nn.Parameter, torch.Tensor]:
     """Gradients of every parameter given d(loss)/d(logits) [B, C]; written into ``sink`` (parameter -> fp32 tensor)
-    when one is given, into fresh tensors otherwise."""
+    when one is given, into fresh tensors otherwise.  ``on_ready(params)`` is called as soon as the gradients of a
+    group of parameters (head + final norm, then each block from the last to the first) are queued."""
     vt: VisionTransformer = model.vit_model
     pe: PatchEmbed = vt.patch_embed
     B, N, M, D, has_cls, cd = S["B"], S["N"], S["M"], S["D"], S["has_cls"], S["cd"]
@@ -371,9 +372,14 @@ def backward_train(model, S: dict, dlogits: torch.Tensor, sink=None) -> Dict[nn.
     else:
         dxc.copy_(dnf[:, :ld] if dnf.shape[1] >= ld else torch.nn.functional.pad(dnf, (0, ld - dnf.shape[1])))
 
+    if on_ready is not None:
+        on_ready(list(model.head.parameters()) + list(vt.norm_final.parameters()))
+
     # ---- blocks, last to first
     for blk, s in zip(reversed(list(vt.blocks)), reversed(S["blocks"])):
         dx = (_pblock_backward if type(blk) is ParallelBlock else _block_backward)(G, blk, s, dx, B, N)
+        if on_ready is not None:
+            on_ready(list(blk.parameters()))
 
     # ---- x0 = LN_pre(xcat) + pos ; xcat = [cls ; LN_e(tok)] ; tok = im2col(img) Wpe^T (+ b)
     dpos = T.colsum(dx.view(B, N * ld), B, N * ld)         # sum over the batch
@@ -522,6 +528,63 @@ class FlatGradients:
             self.flat.div_(dist.get_world_size(group))
 
 
+class GradientReducer:
+    """Data-parallel averaging of a FlatGradients buffer, overlapped with the backward pass.
+
+    The backward produces gradients from the last parameters of the model to the first, and parameters lie in the flat
+    buffer in registration order, so what is ready at any time is a suffix of what is still missing: ``ready(params)``
+    extends the pending range downwards and, once it holds ``bucket_bytes``, starts an asynchronous all-reduce of that
+    contiguous slice (no copies, no per-tensor collectives) while the backward kernels of earlier layers keep running.
+    ``finish()`` reduces what is left and waits.  RCCL over xGMI when the backend is nccl (one process per GPU); over
+    point-to-point xGMI links a collective is per-link bound, so buckets are tens of MB, not the 1 MB of NVSwitch
+    habits."""
+
+    def __init__(self, grads: "FlatGradients", group=None, bucket_bytes: int = 64 << 20):
+        import torch.distributed as dist
+        self.grads, self.group, self.bucket = grads, group, int(bucket_bytes)
+        self.active = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        self.world = dist.get_world_size(group) if self.active else 1
+        self.avg = self.active and dist.get_backend(group) == "nccl"
+        self.offset = {p: o for p, o in zip(grads.params, grads.offsets)}
+        self.begin()
+
+    def begin(self) -> None:
+        self.hi = self.lo = self.grads.flat.numel()     # pending range [lo, hi): ready but not yet sent
+        self.sent_lo = self.hi                          # everything in [sent_lo, end) has been handed to a collective
+        self.works = []
+
+    def _fire(self, lo: int, hi: int) -> None:
+        import torch.distributed as dist
+        if hi <= lo:
+            return
+        seg = self.grads.flat[lo:hi]
+        op = dist.ReduceOp.AVG if self.avg else dist.ReduceOp.SUM
+        self.works.append((dist.all_reduce(seg, op=op, group=self.group, async_op=True), seg))
+        self.sent_lo = lo
+
+    def ready(self, params) -> None:
+        """The gradients of ``params`` are final (their kernels are queued on the current stream)."""
+        if not self.active:
+            return
+        lo = min((self.offset[p] for p in params if p in self.offset), default=self.lo)
+        if lo < self.lo:
+            self.lo = lo
+        if (self.hi - self.lo) * 4 >= self.bucket:
+            self._fire(self.lo, self.hi)
+            self.hi = self.lo
+
+    def finish(self) -> None:
+        """Reduce whatever has not been sent (down to the start of the buffer) and wait for every collective."""
+        if not self.active:
+            return
+        self._fire(0, self.hi)
+        for work, seg in self.works:
+            work.wait()
+            if not self.avg:                    # gloo rehearsal: sum, then divide
+                seg.div_(self.world)
+        self.begin()
+
+
 class FlatParameters:
     """Every parameter's storage moved (values kept) into one flat fp32 buffer, each ``p.data`` a view of it: one kernel
     can then update the whole model.  ``load_state_dict`` and in-place edits keep the views; ``model.to()`` / ``.float()``
@@ -655,7 +718,7 @@ class Trainer:
     """One object for the loop body of train.py:215-224 (plus the data-parallel all-reduce)."""
 
     def __init__(self, model, optimizer, scheduler=None, max_norm: float = 1.0, group=None,
-                 compute_dtype: Optional[torch.dtype] = None):
+                 compute_dtype: Optional[torch.dtype] = None, bucket_bytes: int = 64 << 20):
         self.model, self.optimizer, self.scheduler, self.max_norm, self.group = model, optimizer, scheduler, max_norm, group
         self.compute_dtype = compute_dtype          # None: follow the images (fp32 images -> fp32, bf16 -> mixed precision)
         self.grads = FlatGradients(model.parameters())
@@ -666,6 +729,7 @@ class Trainer:
                 self.params = flat
         self.criterion = CrossEntropyLoss()
         self.last_grad_norm = None
+        self.reducer = GradientReducer(self.grads, group, bucket_bytes)
 
     def step(self, images: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
         """zero_grad, forward, loss, backward, all-reduce, clip, optimizer and scheduler step.  The backward kernels
@@ -675,12 +739,12 @@ class Trainer:
             self.grads.attach()
             logits, S = forward_train(self.model, images, cd)
             loss, dl = T.cross_entropy(logits, labels, want_grad=True)
-            G = backward_train(self.model, S, dl, sink=self.grads.views)
+            G = backward_train(self.model, S, dl, sink=self.grads.views, on_ready=self.reducer.ready)
+            loss = loss.reshape(())
+            self.reducer.finish()                    # the gradient all-reduce ran in buckets under the backward
             for p in self.grads.params:              # a parameter the backward did not reach keeps no stale gradient
                 if p not in G:
                     self.grads.views[p].zero_()
-            loss = loss.reshape(())
-        self.grads.all_reduce(self.group)
         self.last_grad_norm = self.grads.clip_grad_norm_(self.max_norm)
         self.optimizer.step()
         if self.scheduler is not None:
