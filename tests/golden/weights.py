@@ -27,6 +27,10 @@ CONFIGS: Dict[str, dict] = {
     # the reference's own CIFAR recipe (training/train.py:167-175): head_dim 96, hidden int(768*0.8)=614
     "cifar_recipe": dict(image_size=32, patch_size=4, embed_dim=768, num_heads=8, depth=1, mlp_ratio=0.8,
                          num_classes=10, embed_norm=True, norm_pre=True, final_norm=True, patch_bias=False),
+    # the same recipe at the depth the reference trains (VisionTransformer's default depth 12): the workload of
+    # `python -m vitm.training.train` itself; bench-only (no fixture)
+    "cifar_recipe_full": dict(image_size=32, patch_size=4, embed_dim=768, num_heads=8, depth=12, mlp_ratio=0.8,
+                              num_classes=10, embed_norm=True, norm_pre=True, final_norm=True, patch_bias=False),
     # BASELINE config 2: ViT-S/16 224 (embedding forward)
     "vit_s16": dict(image_size=224, patch_size=16, embed_dim=384, num_heads=6, depth=12, mlp_ratio=4.0,
                     num_classes=1000, embed_norm=False, norm_pre=True, final_norm=True, patch_bias=False),
