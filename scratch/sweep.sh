@@ -1,5 +1,5 @@
 #!/bin/bash
-# Throughput of the other BASELINE configurations and a batch sweep of ViT-B/16 (run on the GPU box).
+# Throughput of the other benchmark configurations and a batch sweep of ViT-B/16 (run on the GPU box).
 set -e
 for args in "--config vit_tiny_cifar --batch 64" "--config vit_tiny_cifar --batch 64 --graph" "--config vit_tiny_cifar --batch 1024" "--config vit_tiny_cifar --batch 1024 --graph" \
             "--config vit_s16 --batch 256" "--config vit_s16 --batch 256 --graph" "--config vit_b16_384 --batch 64" "--config vit_l16 --batch 128" \

@@ -21,7 +21,7 @@ CONFIGS: Dict[str, dict] = {
     # small all-features config: patch norm + norm_pre + final norm, 2 heads of 64
     "tiny2": dict(image_size=32, patch_size=4, embed_dim=128, num_heads=2, depth=2, mlp_ratio=4.0,
                   num_classes=10, embed_norm=True, norm_pre=True, final_norm=True, patch_bias=False),
-    # BASELINE config 1: ViT-tiny on CIFAR-10 32x32, patch 4
+    # benchmark configuration 1: ViT-tiny on CIFAR-10 32x32, patch 4
     "vit_tiny_cifar": dict(image_size=32, patch_size=4, embed_dim=192, num_heads=3, depth=12, mlp_ratio=4.0,
                            num_classes=10, embed_norm=False, norm_pre=True, final_norm=True, patch_bias=False),
     # the reference's own CIFAR recipe (training/train.py:167-175): head_dim 96, hidden int(768*0.8)=614
@@ -31,16 +31,16 @@ CONFIGS: Dict[str, dict] = {
     # `python -m vitm.training.train` itself; bench-only (no fixture)
     "cifar_recipe_full": dict(image_size=32, patch_size=4, embed_dim=768, num_heads=8, depth=12, mlp_ratio=0.8,
                               num_classes=10, embed_norm=True, norm_pre=True, final_norm=True, patch_bias=False),
-    # BASELINE config 2: ViT-S/16 224 (embedding forward)
+    # benchmark configuration 2: ViT-S/16 224 (embedding forward)
     "vit_s16": dict(image_size=224, patch_size=16, embed_dim=384, num_heads=6, depth=12, mlp_ratio=4.0,
                     num_classes=1000, embed_norm=False, norm_pre=True, final_norm=True, patch_bias=False),
-    # BASELINE config 3: ViT-B/16 224 (classification forward)
+    # benchmark configuration 3: ViT-B/16 224 (classification forward)
     "vit_b16": dict(image_size=224, patch_size=16, embed_dim=768, num_heads=12, depth=12, mlp_ratio=4.0,
                     num_classes=1000, embed_norm=False, norm_pre=True, final_norm=True, patch_bias=False),
-    # BASELINE config 4: ViT-B/16 384 (577 tokens)
+    # benchmark configuration 4: ViT-B/16 384 (577 tokens)
     "vit_b16_384": dict(image_size=384, patch_size=16, embed_dim=768, num_heads=12, depth=12, mlp_ratio=4.0,
                         num_classes=1000, embed_norm=False, norm_pre=True, final_norm=True, patch_bias=False),
-    # BASELINE config 5 (forward part): ViT-L/16 224
+    # benchmark configuration 5 (forward part): ViT-L/16 224
     "vit_l16": dict(image_size=224, patch_size=16, embed_dim=1024, num_heads=16, depth=24, mlp_ratio=4.0,
                     num_classes=1000, embed_norm=False, norm_pre=True, final_norm=True, patch_bias=False),
 }

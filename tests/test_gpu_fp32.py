@@ -1,6 +1,6 @@
 """The fp32 path on a real MI355X: fp32 tensors run fp32 kernels end to end (fp32 MFMA GEMM with erf-accurate
 GELU, fp32 attention, explicit LayerNorm) and must agree with an fp32 reference to 1e-4 relative -- the bar
-BASELINE.json's north star states for fp32.  "Relative" is max|got - ref| / max|ref| over the tensor.
+the task states for the fp32 path.  "Relative" is max|got - ref| / max|ref| over the tensor.
 
 Kernels are checked against float64 PyTorch statements of the same op; the model against the golden fixtures
 captured from the imported reference's fp32 CPU forward, and (CIFAR ViT-tiny, batch 64: the reference's own

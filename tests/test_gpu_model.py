@@ -1,7 +1,7 @@
 """End-to-end parity of the HIP forward on a real MI355X.
 
 Against (a) the golden fixtures captured from the imported reference and (b) the CPU oracle on the same
-seeded inputs.  Tolerances for the bf16 path follow BASELINE.json's north star -- logits within 2e-2 max-abs
+seeded inputs.  Tolerances for the bf16 path are the task's stated ones -- logits within 2e-2 max-abs
 and embedding cosine >= 0.999 per token row -- with the logit bar made scale-aware: 2e-2 * max(1, max|logit|).
 The synthetic "trained-like" weights give logits up to |3.6|, where one bf16 ulp is already 1.6e-2, and the
 reference's OWN bf16 forward (module.bfloat16() on the CPU, stored in the fixtures as ``logits_ref_bf16``)
