@@ -276,3 +276,23 @@ def test_qk_norm_backward(T, dt, M, H, hd):
     assert torch.equal(d[:, 2 * D:], base[:, 2 * D:]), "v gradients untouched"
     for got, ref in zip(outs, p64):
         assert _rel(got, ref.grad) <= 1e-4
+
+
+@pytest.mark.parametrize("M,N,K", [(200, 136, 128), (65, 192, 614), (12608, 768, 3072), (197 * 8, 768, 3072)])
+def test_linear_dx_with_fused_gelu_backward(T, M, N, K):
+    """dpre = (dy . W) * GELU'(pre) in the GEMM epilogue (both the 128x128 and the persistent 256x256 kernel)."""
+    from vitm_amd import _ops
+    dy = _rand(M, N, seed=71).to(BF)
+    w = (_rand(N, K, seed=72) * N ** -0.5).to(BF).float()
+    kp = _ops.round_up(K, 64)
+    pre = torch.zeros((M, kp), device=DEV, dtype=BF)
+    pre[:, :K] = (_rand(M, K, seed=73) * 2).to(BF)
+    p64 = pre[:, :K].double().requires_grad_(True)
+    F.gelu(p64).backward(dy.double() @ w.double())
+    got = T.linear_dx(dy, w, M, gelu_input=pre)
+    assert got.dtype == BF and _rel(got[:, :K], p64.grad) <= 2e-2
+    # against the unfused pair of kernels, to bf16 rounding of the intermediate
+    dh = T.linear_dx(dy, w, M)
+    ref = torch.empty_like(dh)
+    T.gelu_bwd(pre, dh, ref, M, K)
+    assert _rel(got[:, :K], ref[:, :K].double()) <= 2e-2

@@ -79,6 +79,31 @@ __device__ __forceinline__ f32x2_t gelu_erf2(f32x2_t x) {
   phi.y = fmaxf(phi.y, 0.0f);
   return x * phi;
 }
+
+// d/dx GELU(x) = Phi(x) + x * phi(x), two values at a time: Phi from the same polynomial as gelu_erf2 (|error| <= 2e-5),
+// phi(x) = exp(-x^2 / 2) / sqrt(2 pi) through v_exp_f32.  For bf16 gradients.
+__device__ __forceinline__ f32x2_t dgelu_erf2(f32x2_t x) {
+  f32x2_t xc;
+  xc.x = __builtin_amdgcn_fmed3f(x.x, -4.0f, 4.0f);
+  xc.y = __builtin_amdgcn_fmed3f(x.y, -4.0f, 4.0f);
+  const f32x2_t t = xc * xc;
+  f32x2_t q = t * 8.065587196e-11f + -7.004855253e-09f;
+  q = q * t + 2.716520232e-07f;
+  q = q * t + -6.295502535e-06f;
+  q = q * t + 9.891200638e-05f;
+  q = q * t + -1.133939351e-03f;
+  q = q * t + 9.877516551e-03f;
+  q = q * t + -6.641063552e-02f;
+  q = q * t + 3.989227214e-01f;
+  f32x2_t phi = xc * q + (0.5f - 2.5e-5f);
+  phi.x = fmaxf(phi.x, 0.0f);
+  phi.y = fmaxf(phi.y, 0.0f);
+  const f32x2_t x2 = x * x;
+  f32x2_t pdf;
+  pdf.x = 0.3989422804f * __builtin_amdgcn_exp2f(-0.72134752f * x2.x);
+  pdf.y = 0.3989422804f * __builtin_amdgcn_exp2f(-0.72134752f * x2.y);
+  return phi + x * pdf;
+}
 // the same function on NP independent pairs with the Horner steps interleaved across pairs (one dependent chain
 // per pair would leave the packed-math pipe waiting on itself)
 template <int NP>

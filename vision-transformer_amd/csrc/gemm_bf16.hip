@@ -239,6 +239,7 @@ int dispatch(const GemmArgs& a, int epi, int out_f32, hipStream_t st) {
     case VITM_EPI_LN: return launch<VITM_EPI_LN, AMODE, 0>(a, st);
     case VITM_EPI_LN_GELU: return launch<VITM_EPI_LN_GELU, AMODE, 0>(a, st);
     case VITM_EPI_RESIDUAL: return launch<VITM_EPI_RESIDUAL, AMODE, 0>(a, st);
+    case VITM_EPI_DGELU: return launch<VITM_EPI_DGELU, AMODE, 0>(a, st);
     default: break;
   }
   vitm_set_error("vitm_gemm: unknown epilogue %d", epi);
@@ -269,6 +270,8 @@ extern "C" int vitm_gemm(const void* A, int64_t lda, const void* Wp, int64_t ldw
                "vitm_gemm: LN epilogue needs stats and s (16-byte aligned)");
   VITM_REQUIRE(epilogue != VITM_EPI_RESIDUAL || (resid && g && aligned16(resid) && aligned16(g) && ldr >= N && ldr % 8 == 0),
                "vitm_gemm: RESIDUAL epilogue needs resid (ldr >= N, multiple of 8) and g");
+  VITM_REQUIRE(epilogue != VITM_EPI_DGELU || (resid && aligned16(resid) && ldr >= N && ldr % 8 == 0 && out_dtype == VITM_BF16),
+               "vitm_gemm: DGELU epilogue needs resid (the GELU input, ldr >= N, multiple of 8) and bf16 output");
   VITM_REQUIRE(row_group >= 0, "vitm_gemm: row_group must be >= 0");
   GemmArgs a{};
   a.A = (const bf16_t*)A; a.lda = lda; a.W = (const bf16_t*)Wp; a.ldw = ldw;

@@ -60,7 +60,7 @@ struct EpiCols {
   __device__ __forceinline__ void finish(const GemmArgs& p, int m, int n, float* v) const {
     u16x8_t rv = {0, 0, 0, 0, 0, 0, 0, 0};
     float2 st = make_float2(0.f, 1.f);
-    if (EPI == VITM_EPI_RESIDUAL) rv = *(const u16x8_t*)(p.resid + (int64_t)m * p.ldr + n);
+    if (EPI == VITM_EPI_RESIDUAL || EPI == VITM_EPI_DGELU) rv = *(const u16x8_t*)(p.resid + (int64_t)m * p.ldr + n);
     if (EPI == VITM_EPI_LN || EPI == VITM_EPI_LN_GELU) st = *(const float2*)(p.stats + 2 * (int64_t)m);
     finish_pre<OUT_F32>(p, m, n, v, rv, st);
   }
@@ -85,6 +85,14 @@ struct EpiCols {
     if (EPI == VITM_EPI_RESIDUAL) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = bf2f(rv[e]) + fmaf(gv[e], v[e], cv[e]);
+    }
+    if (EPI == VITM_EPI_DGELU) {
+#pragma unroll
+      for (int e = 0; e < 8; e += 2) {
+        const f32x2_t d = dgelu_erf2((f32x2_t){bf2f(rv[e]), bf2f(rv[e + 1])});
+        v[e] *= d.x;
+        v[e + 1] *= d.y;
+      }
     }
     const int64_t om = p.row_group > 0 ? (int64_t)m + m / p.row_group + 1 : (int64_t)m;
     if (OUT_F32) {

@@ -372,7 +372,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_pp_kernel(const GemmArgs p) {
     for (int j = 0; j < 4; ++j) {
       int n = ncol + 16 * j;
       n = n < p.N ? n : p.N - 4;   // N % 8 == 0: a clamped quad is computed but never stored
-      cq[j] = *(const float4*)(p.c + n);
+      if (EPI != VITM_EPI_DGELU) cq[j] = *(const float4*)(p.c + n);
       if (EPI == VITM_EPI_LN || EPI == VITM_EPI_LN_GELU) sq[j] = *(const float4*)(p.s + n);
       if (EPI == VITM_EPI_RESIDUAL) gq[j] = *(const float4*)(p.g + n);
     }
@@ -386,7 +386,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_pp_kernel(const GemmArgs p) {
       }
     }
     const bool stores_on = (PP_ABLATE & 4) == 0;
-    if (EPI != VITM_EPI_RESIDUAL) {
+    if (EPI != VITM_EPI_RESIDUAL && EPI != VITM_EPI_DGELU) {
 #pragma unroll
       for (int i = 0; i < NBLK; ++i) {
         f32x2_t v[8];  // the 16 values of row i: pairs (j, half)
@@ -428,7 +428,8 @@ __global__ __launch_bounds__(NT, 2) void gemm_pp_kernel(const GemmArgs p) {
     } else {
       // residual: out = resid + (g * acc + c), one rounding.  The fp32 values are swapped (4 dwords per quad) so
       // the residual is read and the result written as 16 bytes per lane.  Two halves of 4 rows keep the
-      // residual values of a half in registers before its first store.
+      // residual values of a half in registers before its first store.  DGELU uses the same layout with
+      // out = acc * gelu'(resid).
       constexpr int I4 = NBLK < 4 ? NBLK : 4, IH = NBLK / I4;
 #pragma unroll
       for (int ih = 0; ih < IH; ++ih) {
@@ -452,8 +453,13 @@ __global__ __launch_bounds__(NT, 2) void gemm_pp_kernel(const GemmArgs p) {
             const float g1[4] = {gq[1].x, gq[1].y, gq[1].z, gq[1].w}, cc1[4] = {cq[1].x, cq[1].y, cq[1].z, cq[1].w};
             const float g2[4] = {gq[2].x, gq[2].y, gq[2].z, gq[2].w}, cc2[4] = {cq[2].x, cq[2].y, cq[2].z, cq[2].w};
             const float g3[4] = {gq[3].x, gq[3].y, gq[3].z, gq[3].w}, cc3[4] = {cq[3].x, cq[3].y, cq[3].z, cq[3].w};
-            float l0 = fmaf(g0[e], acc[i][0][e], cc0[e]), h0 = fmaf(g1[e], acc[i][1][e], cc1[e]);
-            float l1 = fmaf(g2[e], acc[i][2][e], cc2[e]), h1 = fmaf(g3[e], acc[i][3][e], cc3[e]);
+            float l0, h0, l1, h1;
+            if (EPI == VITM_EPI_DGELU) {
+              l0 = acc[i][0][e]; h0 = acc[i][1][e]; l1 = acc[i][2][e]; h1 = acc[i][3][e];
+            } else {
+              l0 = fmaf(g0[e], acc[i][0][e], cc0[e]); h0 = fmaf(g1[e], acc[i][1][e], cc1[e]);
+              l1 = fmaf(g2[e], acc[i][2][e], cc2[e]); h1 = fmaf(g3[e], acc[i][3][e], cc3[e]);
+            }
             swap16(l0, h0);
             swap16(l1, h1);
             lo0[e] = __builtin_bit_cast(unsigned, l0);
@@ -469,6 +475,19 @@ __global__ __launch_bounds__(NT, 2) void gemm_pp_kernel(const GemmArgs p) {
             const unsigned* l4 = h ? lo1 : lo0;
             const unsigned* h4 = h ? hi1 : hi0;
             uint4 o;
+            if (EPI == VITM_EPI_DGELU) {
+              const unsigned rw[4] = {rv.x, rv.y, rv.z, rv.w};
+              unsigned ow[4];
+#pragma unroll
+              for (int w2 = 0; w2 < 4; ++w2) {
+                const unsigned* a4 = w2 < 2 ? l4 : h4;
+                const f32x2_t d = dgelu_erf2((f32x2_t){__builtin_bit_cast(float, rw[w2] << 16),
+                                                       __builtin_bit_cast(float, rw[w2] & 0xffff0000u)});
+                ow[w2] = pack_bf2(__builtin_bit_cast(float, a4[2 * (w2 & 1)]) * d.x,
+                                  __builtin_bit_cast(float, a4[2 * (w2 & 1) + 1]) * d.y);
+              }
+              o = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+            } else {
             o.x = pack_bf2(__builtin_bit_cast(float, rv.x << 16) + __builtin_bit_cast(float, l4[0]),
                            __builtin_bit_cast(float, rv.x & 0xffff0000u) + __builtin_bit_cast(float, l4[1]));
             o.y = pack_bf2(__builtin_bit_cast(float, rv.y << 16) + __builtin_bit_cast(float, l4[2]),
@@ -477,6 +496,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_pp_kernel(const GemmArgs p) {
                            __builtin_bit_cast(float, rv.z & 0xffff0000u) + __builtin_bit_cast(float, h4[1]));
             o.w = pack_bf2(__builtin_bit_cast(float, rv.w << 16) + __builtin_bit_cast(float, h4[2]),
                            __builtin_bit_cast(float, rv.w & 0xffff0000u) + __builtin_bit_cast(float, h4[3]));
+            }
             const int m = mst + 16 * i + 8 * h;
             if (stores_on && m < p.M && nst < p.N && (!SLICE || (i0 + i >= is0 && i0 + i < is1)))
               store_out((bf16_t*)p.out + (int64_t)m * p.ldo + nst, o.x, o.y, o.z, o.w);
@@ -556,6 +576,7 @@ int vitm_gemm_pp_launch(const GemmArgs& a, int epilogue, hipStream_t st) {
     case VITM_EPI_LN: return launch<VITM_EPI_LN>(a, st);
     case VITM_EPI_LN_GELU: return launch<VITM_EPI_LN_GELU>(a, st);
     case VITM_EPI_RESIDUAL: return launch<VITM_EPI_RESIDUAL>(a, st);
+    case VITM_EPI_DGELU: return launch<VITM_EPI_DGELU>(a, st);
     default: break;
   }
   vitm_set_error("vitm_gemm: unknown epilogue %d", epilogue);

@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get(
     "VITM_GFX950_LIB", os.path.join(os.path.dirname(_HERE), "lib", "libvitm_gfx950.so"))
 
 BF16, F32 = 0, 1
-EPI_BIAS, EPI_BIAS_GELU, EPI_LN, EPI_LN_GELU, EPI_RESIDUAL = 0, 1, 2, 3, 4
+EPI_BIAS, EPI_BIAS_GELU, EPI_LN, EPI_LN_GELU, EPI_RESIDUAL, EPI_DGELU = 0, 1, 2, 3, 4, 5
 
 
 class VitmLibraryError(RuntimeError):

@@ -9,7 +9,7 @@ from typing import Optional
 import torch
 
 from . import _lib
-from ._ops import _p, _dt, _stream, round_up, k_multiple, pack_linear, gemm, to_f32, to_bf16, EPI_BIAS, PackedLinear
+from ._ops import _p, _dt, _stream, round_up, k_multiple, pack_linear, gemm, to_f32, to_bf16, EPI_BIAS, EPI_DGELU, PackedLinear
 
 COLSUM_CHUNKS = 64
 COLSUM_WORKGROUPS = 1024
@@ -171,9 +171,12 @@ def adamw(p, g, m, v, lr, beta1, beta2, eps, wd, step) -> None:
 
 
 # ---- Linear backward out of the forward GEMM ----------------------------------------------------------------------
-def linear_dx(dy: torch.Tensor, weight: torch.Tensor, M: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+def linear_dx(dy: torch.Tensor, weight: torch.Tensor, M: int, out: Optional[torch.Tensor] = None,
+              gelu_input: Optional[torch.Tensor] = None) -> torch.Tensor:
     """dx[M, K] = dy[M, N] . W[N, K]  (nn.Linear weight layout): the forward GEMM with W^T as the packed operand.
-    dy's dtype is the compute dtype (the fp32 master weight is packed to it); dx comes back in it."""
+    dy's dtype is the compute dtype (the fp32 master weight is packed to it); dx comes back in it.
+    ``gelu_input`` (bf16 [M, >= K], the pre-activation of the GELU whose output fed this Linear) makes the epilogue
+    multiply by GELU'(gelu_input): the result is the gradient wrt the pre-activation, with no separate pass."""
     N, K = weight.shape
     # W^T in the compute dtype, K of the GEMM (= N) padded to its multiple, rows (= K) padded to 8: one kernel
     kpad, npad = round_up(N, k_multiple()), round_up(K, 8)
@@ -185,7 +188,11 @@ def linear_dx(dy: torch.Tensor, weight: torch.Tensor, M: int, out: Optional[torc
         dyp[:, :dy.shape[1]] = dy
     if out is None:
         out = torch.empty((M, pk.npad), dtype=dy.dtype, device=dy.device)
-    gemm(dyp, pk, out, EPI_BIAS, M)
+    if gelu_input is not None:
+        assert dy.dtype == torch.bfloat16 and gelu_input.dtype == torch.bfloat16 and gelu_input.shape[1] >= pk.npad
+        gemm(dyp, pk, out, EPI_DGELU, M, resid=gelu_input)
+    else:
+        gemm(dyp, pk, out, EPI_BIAS, M)
     return out
 
 

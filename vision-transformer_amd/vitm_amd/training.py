@@ -242,9 +242,13 @@ def _block_backward(G: _Grads, blk: Block, s: dict, dx2: torch.Tensor, B: int, N
     T.colsum(dx2, M, D, s["z2"], out=G.buf(blk.ls2.gamma))
     dz2 = torch.empty((M, _ops.round_up(D, 8)), dtype=cd, device=dev)
     _ops.scale_channels(dx2[:, :dz2.shape[1]] if dx2.shape[1] != dz2.shape[1] else dx2, dz2, M, _ops.round_up(D, 8), _pad8(g2))
-    dh = _linear_backward(G, mlp.linear_layer2, dz2, s["h"], M)
-    dpre = dh                                             # in place: element-wise
-    T.gelu_bwd(s["pre"], dh, dpre, M, hid)
+    if cd == torch.bfloat16:      # GELU backward in the epilogue of the input-gradient GEMM
+        _linear_backward(G, mlp.linear_layer2, dz2, s["h"], M, need_dx=False)
+        dpre = T.linear_dx(dz2, mlp.linear_layer2.weight, M, gelu_input=s["pre"])
+    else:
+        dh = _linear_backward(G, mlp.linear_layer2, dz2, s["h"], M)
+        dpre = dh                                         # in place: element-wise
+        T.gelu_bwd(s["pre"], dh, dpre, M, hid)
     dn2 = _linear_backward(G, mlp.linear_layer1, dpre, s["n2"], M)
     dx1 = _buf(M, D, dev, cd)
     if ln2 is not None:
@@ -315,10 +319,15 @@ def _pblock_backward(G: _Grads, blk: ParallelBlock, s: dict, dx2: torch.Tensor, 
     # attention half: cat[:, :D] = attn.proj(o)
     d_o = _linear_backward(G, blk.attn.proj, dcat[:, :D], s["o"], M)
     # MLP half: cat[:, D:2D] = out_proj(gelu(pre))
-    dh = _linear_backward(G, blk.mlp.out_proj, dcat[:, D:2 * D], s["h"], M)
     # gradient of the fused first projection's output, [q | k | v | hidden] side by side like its weight rows
     d1 = _buf(M, 3 * D + hid, dev, cd)
-    T.gelu_bwd(s["pre"], dh, d1[:, 3 * D:3 * D + hid], M, hid)
+    if cd == torch.bfloat16:      # GELU backward in the epilogue of the input-gradient GEMM, written in place
+        _linear_backward(G, blk.mlp.out_proj, dcat[:, D:2 * D], s["h"], M, need_dx=False)
+        T.linear_dx(dcat[:, D:2 * D], blk.mlp.out_proj.weight, M, out=d1[:, 3 * D:3 * D + _ops.round_up(hid, 8)],
+                    gelu_input=s["pre"])
+    else:
+        dh = _linear_backward(G, blk.mlp.out_proj, dcat[:, D:2 * D], s["h"], M)
+        T.gelu_bwd(s["pre"], dh, d1[:, 3 * D:3 * D + hid], M, hid)
     _attention_backward(G, blk.attn, s, d_o, d1[:, :3 * D], B, N, "ParallelBlockMultiHeadAttention")
     dn = _linear_backward(G, blk.fused_proj_1, d1, s["n"], M)
     dx = _buf(M, D, dev, cd)
