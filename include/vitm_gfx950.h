@@ -238,19 +238,23 @@ int vitm_attention_bwd(const void* qkv, int64_t ldqkv, const void* o, int64_t ld
  * Weight gradient of a Linear layer without transposed copies: out[n, k] (fp32) = sum_m a[m, n] * b[m, k] for bf16
  * row-major a (M x N, dy) and b (M x K, the layer's input); backward of models.py:76,94,127,129 and classifier.py:38.
  * colsum_out (nullable, N floats) receives sum_m a[m, n], the bias gradient, from the same pass over a.
+ * row_scale (nullable, N floats) multiplies row n of out and colsum_out[n]: a LayerScale between the Linear and the
+ * gradient that arrives (dy = upstream * gamma) without materialising dy.
  * lda and ldb are multiples of 8.  The reduction over m is split over workgroup slices whose fp32 partial results go to
  * `workspace` (vitm_gemm_tn_workspace_floats(M, N, K) floats, 0 when one slice is enough) and are added in a fixed order.
  */
 int vitm_gemm_tn(const void* a, int64_t lda, const void* b, int64_t ldb, float* out, int64_t ldo, float* colsum_out,
-                 int M, int N, int K, float* workspace, int64_t workspace_floats, vitm_stream_t stream);
+                 const float* row_scale, int M, int N, int K, float* workspace, int64_t workspace_floats,
+                 vitm_stream_t stream);
 int64_t vitm_gemm_tn_workspace_floats(int M, int N, int K);
 
 /*
  * dst[n, m] = src[m, n] for m < M, zero for M <= m < m_pad (K padding of a GEMM operand), converting src_dtype to
  * dst_dtype on the way: W^T of an fp32 master weight as the bf16 operand of the input-gradient GEMM in one pass.
+ * row_scale (nullable, M floats) multiplies source row m (a LayerScale folded into W^T).
  */
 int vitm_transpose(const void* src, int src_dtype, int64_t lds, void* dst, int dst_dtype, int64_t ldd, int M, int N,
-                   int m_pad, vitm_stream_t stream);
+                   int m_pad, const float* row_scale, vitm_stream_t stream);
 
 /*
  * out[c, d] = sum over the rows m of chunk c (nchunks equal chunks of the M rows) of a[m, d] * (b ? b[m, d] : 1).

@@ -296,3 +296,20 @@ def test_linear_dx_with_fused_gelu_backward(T, M, N, K):
     ref = torch.empty_like(dh)
     T.gelu_bwd(pre, dh, ref, M, K)
     assert _rel(got[:, :K], ref[:, :K].double()) <= 2e-2
+
+
+def test_layerscale_folded_into_linear_backward(T):
+    """dy * gamma never materialised: gamma scales W^T's source rows (input gradient) and the rows of dW / db."""
+    M, N, K = 1500, 768, 256
+    dy = _rand(M, N, seed=81).to(BF)
+    x = _rand(M, K, seed=82).to(BF)
+    w = (_rand(N, K, seed=83) * N ** -0.5).to(BF).float()
+    gam = 1 + 0.3 * _rand(N, seed=84)
+    dz = dy.double() * gam.double()
+    db = torch.full((N,), float("nan"), device=DEV)
+    dw = T.linear_dw(dy, x, M, N, K, bias_out=db, dy_scale=gam)
+    assert _rel(dw, dz.t() @ x.double()) <= 1e-5 and _rel(db, dz.sum(0)) <= 1e-5
+    dx = T.linear_dx(dy, w, M, dy_scale=gam)
+    assert _rel(dx[:, :K], dz @ w.double()) <= 2e-2
+    wt = T.transpose(w, N, K, 832, out_dtype=BF, row_scale=gam)
+    assert _rel(wt[:, :N], (w.double() * gam.double()[:, None]).t()) <= 1e-2 and (wt[:, N:] == 0).all()

@@ -47,8 +47,8 @@ __device__ __forceinline__ bf16x8_t tn_frag(const char* a0) {
 template <int BN_, int BK_, int FI, int DEPTH>
 __global__ __launch_bounds__((BN_ / (32 * FI)) * (BK_ / 64) * 64, BN_ == 128 ? 2 : 1) void gemm_tn_kernel(
     const bf16_t* __restrict__ a, int64_t lda, const bf16_t* __restrict__ b, int64_t ldb, float* __restrict__ dst,
-    int64_t ldd, int64_t slice_stride, float* __restrict__ csum, int M, int N, int K, int rows_per_slice, int tiles_k,
-    int nslices, int npairs) {
+    int64_t ldd, int64_t slice_stride, float* __restrict__ csum, const float* __restrict__ row_scale, int M, int N,
+    int K, int rows_per_slice, int tiles_k, int nslices, int npairs) {
   constexpr int WK_ = BK_ / 64;                      // waves along the output columns
   constexpr int NT_ = (BN_ / (32 * FI)) * WK_ * 64;  // threads
   constexpr int RSA = BN_ * 2 + 64, RSB = BK_ * 2 + 64;     // LDS row strides (bytes): 64 mod 256
@@ -197,7 +197,7 @@ __global__ __launch_bounds__((BN_ / (32 * FI)) * (BK_ / 64) * 64, BN_ == 128 ? 2
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int n = n0 + 32 * FI * wn + 32 * (2 * wk + i) + (e & 3) + 8 * (e >> 2) + 4 * hh;
-        if (n < N) co[n] = cacc[i][e];
+        if (n < N) co[n] = cacc[i][e] * (row_scale ? row_scale[n] : 1.0f);
       }
   }
   float* out = dst + (int64_t)slice * slice_stride;
@@ -210,7 +210,7 @@ __global__ __launch_bounds__((BN_ / (32 * FI)) * (BK_ / 64) * 64, BN_ == 128 ? 2
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int n = n0 + 32 * FI * wn + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * hh;
-        if (n < N) out[(int64_t)n * ldd + kc] = acc[i][j][e];
+        if (n < N) out[(int64_t)n * ldd + kc] = acc[i][j][e] * (row_scale ? row_scale[n] : 1.0f);
       }
     }
 }
@@ -273,15 +273,15 @@ TnPlan tn_plan(int M, int N, int K) {
 
 template <int BN_, int BK_, int FI>
 int tn_launch(const TnPlan& p, const bf16_t* a, int64_t lda, const bf16_t* b, int64_t ldb, float* dst, int64_t ldd,
-              int64_t slice_stride, float* csum, int M, int N, int K, hipStream_t st) {
+              int64_t slice_stride, float* csum, const float* row_scale, int M, int N, int K, hipStream_t st) {
   constexpr int SMEM_ = 2 * TN_BM * ((BN_ * 2 + 64) + (BK_ * 2 + 64));
   constexpr int DEPTH_ = BN_ == 256 ? 1 : TN_DEPTH;   // the 256 x 256 tile's accumulators leave registers for one step
   auto kfn = gemm_tn_kernel<BN_, BK_, FI, DEPTH_>;
   VITM_LDS_OPTIN(kfn, SMEM_, "vitm_gemm_tn");
   const int npairs = p.tiles_n * p.tiles_k * p.slices;
   const dim3 grid((unsigned)(8 * ((npairs + 7) / 8)));
-  hipLaunchKernelGGL(kfn, grid, dim3((BN_ / (32 * FI)) * (BK_ / 64) * 64), SMEM_, st, a, lda, b, ldb, dst, ldd, slice_stride, csum, M, N, K,
-                     p.rows_per_slice, p.tiles_k, p.slices, npairs);
+  hipLaunchKernelGGL(kfn, grid, dim3((BN_ / (32 * FI)) * (BK_ / 64) * 64), SMEM_, st, a, lda, b, ldb, dst, ldd, slice_stride, csum, row_scale, M,
+                     N, K, p.rows_per_slice, p.tiles_k, p.slices, npairs);
   VITM_CHECK_LAUNCH("vitm_gemm_tn");
   return VITM_OK;
 }
@@ -295,8 +295,8 @@ extern "C" int64_t vitm_gemm_tn_workspace_floats(int M, int N, int K) {
 }
 
 extern "C" int vitm_gemm_tn(const void* a, int64_t lda, const void* b, int64_t ldb, float* out, int64_t ldo,
-                            float* colsum_out, int M, int N, int K, float* workspace, int64_t workspace_floats,
-                            vitm_stream_t stream) {
+                            float* colsum_out, const float* row_scale, int M, int N, int K, float* workspace,
+                            int64_t workspace_floats, vitm_stream_t stream) {
   VITM_REQUIRE(a && b && out, "vitm_gemm_tn: null pointer");
   VITM_REQUIRE(M > 0 && N > 0 && K > 0, "vitm_gemm_tn: M, N, K must be positive");
   VITM_REQUIRE(lda >= N && ldb >= K && ldo >= K && lda % 8 == 0 && ldb % 8 == 0,
@@ -315,8 +315,8 @@ extern "C" int vitm_gemm_tn(const void* a, int64_t lda, const void* b, int64_t l
   float* dst = direct ? out : workspace;
   const int64_t ldd = direct ? ldo : (int64_t)K, sstride = direct ? 0 : (int64_t)N * K;
   float* cs = !colsum_out ? nullptr : (direct ? colsum_out : workspace + (int64_t)p.slices * N * K);
-  const int rc = p.bn == 256 ? tn_launch<256, 256, 4>(p, ap, lda, bp, ldb, dst, ldd, sstride, cs, M, N, K, st)
-                             : tn_launch<128, 128, 2>(p, ap, lda, bp, ldb, dst, ldd, sstride, cs, M, N, K, st);
+  const int rc = p.bn == 256 ? tn_launch<256, 256, 4>(p, ap, lda, bp, ldb, dst, ldd, sstride, cs, row_scale, M, N, K, st)
+                             : tn_launch<128, 128, 2>(p, ap, lda, bp, ldb, dst, ldd, sstride, cs, row_scale, M, N, K, st);
   if (rc != VITM_OK || direct) return rc;
   const int64_t total = (int64_t)N * K;
   int64_t g = (total + 255) / 256;

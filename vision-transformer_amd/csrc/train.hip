@@ -52,14 +52,15 @@ inline unsigned stream_grid(int64_t items, int per = 256, int cap = 4096) {
 // ---- transpose: 32x32 tiles through LDS ------------------------------------------------------------------
 template <typename TS, typename TD>
 __global__ __launch_bounds__(256) void transpose_kernel(const TS* __restrict__ src, int64_t lds_, TD* __restrict__ dst,
-                                                        int64_t ldd, int M, int N, int Mpad) {
+                                                        int64_t ldd, int M, int N, int Mpad,
+                                                        const float* __restrict__ row_scale) {
   __shared__ float tile[32][33];
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
   const int m0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int m = m0 + ty + 8 * i, n = n0 + tx;
-    tile[ty + 8 * i][tx] = (m < M && n < N) ? ldv(src + (int64_t)m * lds_ + n) : 0.f;
+    tile[ty + 8 * i][tx] = (m < M && n < N) ? ldv(src + (int64_t)m * lds_ + n) * (row_scale ? row_scale[m] : 1.0f) : 0.f;
   }
   __syncthreads();
 #pragma unroll
@@ -619,7 +620,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
 }  // namespace
 
 extern "C" int vitm_transpose(const void* src, int src_dtype, int64_t lds, void* dst, int dst_dtype, int64_t ldd, int M, int N,
-                              int m_pad, vitm_stream_t stream) {
+                              int m_pad, const float* row_scale, vitm_stream_t stream) {
   VITM_REQUIRE(src && dst, "vitm_transpose: null pointer");
   VITM_REQUIRE((src_dtype == VITM_BF16 || src_dtype == VITM_F32) && (dst_dtype == VITM_BF16 || dst_dtype == VITM_F32),
                "vitm_transpose: bad dtype %d -> %d", src_dtype, dst_dtype);
@@ -628,10 +629,10 @@ extern "C" int vitm_transpose(const void* src, int src_dtype, int64_t lds, void*
   VITM_REQUIRE(grid.y < 65536, "vitm_transpose: N too large");
   hipStream_t st = (hipStream_t)stream;
   const bool sf = src_dtype == VITM_F32, df = dst_dtype == VITM_F32;
-  if (sf && df) hipLaunchKernelGGL((transpose_kernel<float, float>), grid, dim3(256), 0, st, (const float*)src, lds, (float*)dst, ldd, M, N, m_pad);
-  else if (sf) hipLaunchKernelGGL((transpose_kernel<float, bf16_t>), grid, dim3(256), 0, st, (const float*)src, lds, (bf16_t*)dst, ldd, M, N, m_pad);
-  else if (df) hipLaunchKernelGGL((transpose_kernel<bf16_t, float>), grid, dim3(256), 0, st, (const bf16_t*)src, lds, (float*)dst, ldd, M, N, m_pad);
-  else hipLaunchKernelGGL((transpose_kernel<bf16_t, bf16_t>), grid, dim3(256), 0, st, (const bf16_t*)src, lds, (bf16_t*)dst, ldd, M, N, m_pad);
+  if (sf && df) hipLaunchKernelGGL((transpose_kernel<float, float>), grid, dim3(256), 0, st, (const float*)src, lds, (float*)dst, ldd, M, N, m_pad, row_scale);
+  else if (sf) hipLaunchKernelGGL((transpose_kernel<float, bf16_t>), grid, dim3(256), 0, st, (const float*)src, lds, (bf16_t*)dst, ldd, M, N, m_pad, row_scale);
+  else if (df) hipLaunchKernelGGL((transpose_kernel<bf16_t, float>), grid, dim3(256), 0, st, (const bf16_t*)src, lds, (float*)dst, ldd, M, N, m_pad, row_scale);
+  else hipLaunchKernelGGL((transpose_kernel<bf16_t, bf16_t>), grid, dim3(256), 0, st, (const bf16_t*)src, lds, (bf16_t*)dst, ldd, M, N, m_pad, row_scale);
   VITM_CHECK_LAUNCH("vitm_transpose");
   return VITM_OK;
 }

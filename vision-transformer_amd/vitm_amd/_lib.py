@@ -66,10 +66,10 @@ SIGNATURES = {
                                    c_void_p]),
     "vitm_attention_bwd": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64,
                                    c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p]),
-    "vitm_gemm_tn": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int, c_int, c_int, c_void_p,
-                             c_int64, c_void_p]),
+    "vitm_gemm_tn": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int, c_int, c_int,
+                             c_void_p, c_int64, c_void_p]),
     "vitm_gemm_tn_workspace_floats": (c_int64, [c_int, c_int, c_int]),
-    "vitm_transpose": (c_int, [c_void_p, c_int, c_int64, c_void_p, c_int, c_int64, c_int, c_int, c_int, c_void_p]),
+    "vitm_transpose": (c_int, [c_void_p, c_int, c_int64, c_void_p, c_int, c_int64, c_int, c_int, c_int, c_void_p, c_void_p]),
     "vitm_colsum": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
     "vitm_layernorm_bwd": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_float, c_void_p, c_int64, c_void_p,
                                    c_int64, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),

@@ -59,16 +59,16 @@ def _delta(ref, B, H, N):
 
 
 def transpose(src: torch.Tensor, M: int, N: int, m_pad: Optional[int] = None, out_dtype: Optional[torch.dtype] = None,
-              rows: Optional[int] = None) -> torch.Tensor:
+              rows: Optional[int] = None, row_scale: Optional[torch.Tensor] = None) -> torch.Tensor:
     """[M, N] (row stride src.stride(0)) -> new [rows or N, m_pad] in out_dtype (default: the source's) with the pad
-    columns (and pad rows) zero."""
+    columns (and pad rows) zero; ``row_scale`` (M floats) multiplies source row m."""
     m_pad = M if m_pad is None else m_pad
     rows = N if rows is None else rows
     dt = src.dtype if out_dtype is None else out_dtype
     dst = (torch.empty if rows == N else torch.zeros)((rows, m_pad), dtype=dt, device=src.device)
     assert src.stride(-1) == 1
-    _lib.check(_lib.load().vitm_transpose(_p(src), _dt(src), src.stride(0), _p(dst), _dt(dst), m_pad, M, N, m_pad, _stream()),
-               "vitm_transpose")
+    _lib.check(_lib.load().vitm_transpose(_p(src), _dt(src), src.stride(0), _p(dst), _dt(dst), m_pad, M, N, m_pad,
+                                          _p(None if row_scale is None else _f32(row_scale)), _stream()), "vitm_transpose")
     return dst
 
 
@@ -172,15 +172,16 @@ def adamw(p, g, m, v, lr, beta1, beta2, eps, wd, step) -> None:
 
 # ---- Linear backward out of the forward GEMM ----------------------------------------------------------------------
 def linear_dx(dy: torch.Tensor, weight: torch.Tensor, M: int, out: Optional[torch.Tensor] = None,
-              gelu_input: Optional[torch.Tensor] = None) -> torch.Tensor:
+              gelu_input: Optional[torch.Tensor] = None, dy_scale: Optional[torch.Tensor] = None) -> torch.Tensor:
     """dx[M, K] = dy[M, N] . W[N, K]  (nn.Linear weight layout): the forward GEMM with W^T as the packed operand.
     dy's dtype is the compute dtype (the fp32 master weight is packed to it); dx comes back in it.
     ``gelu_input`` (bf16 [M, >= K], the pre-activation of the GELU whose output fed this Linear) makes the epilogue
-    multiply by GELU'(gelu_input): the result is the gradient wrt the pre-activation, with no separate pass."""
+    multiply by GELU'(gelu_input): the result is the gradient wrt the pre-activation, with no separate pass.
+    ``dy_scale`` (N floats) stands for dy * dy_scale (a LayerScale behind the Linear): it is folded into W^T."""
     N, K = weight.shape
     # W^T in the compute dtype, K of the GEMM (= N) padded to its multiple, rows (= K) padded to 8: one kernel
     kpad, npad = round_up(N, k_multiple()), round_up(K, 8)
-    wt = transpose(weight.detach().contiguous(), N, K, kpad, out_dtype=dy.dtype, rows=npad)
+    wt = transpose(weight.detach().contiguous(), N, K, kpad, out_dtype=dy.dtype, rows=npad, row_scale=dy_scale)
     pk = PackedLinear(wt, None, _zeros_f32(dy.device, npad), None, K, N, npad, kpad)
     dyp = dy
     if dy.shape[1] < pk.kpad:                                       # pad dy's columns to the GEMM's K multiple
@@ -201,28 +202,32 @@ def _tn_ok(t: torch.Tensor) -> bool:
 
 
 def gemm_tn(a: torch.Tensor, b: torch.Tensor, M: int, N: int, K: int, out: Optional[torch.Tensor] = None,
-            colsum_out: Optional[torch.Tensor] = None) -> torch.Tensor:
+            colsum_out: Optional[torch.Tensor] = None, row_scale: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out[N, K] (fp32) = a[:M, :N]^T . b[:M, :K] for bf16 row-major a, b: no transposed copies, reduction split over
-    workgroup slices and summed in a fixed order.  ``colsum_out`` (N floats) also receives the column sums of a."""
+    workgroup slices and summed in a fixed order.  ``colsum_out`` (N floats) also receives the column sums of a;
+    ``row_scale`` (N floats) multiplies row n of both results."""
     lib = _lib.load()
     if out is None:
         out = torch.empty((N, K), dtype=F32, device=a.device)
     assert out.stride(1) == 1 and (colsum_out is None or (colsum_out.is_contiguous() and colsum_out.numel() == N))
     nws = lib.vitm_gemm_tn_workspace_floats(M, N, K)
     ws = torch.empty(nws, dtype=F32, device=a.device) if nws else None
-    _lib.check(lib.vitm_gemm_tn(_p(a), a.stride(0), _p(b), b.stride(0), _p(out), out.stride(0), _p(colsum_out), M, N, K,
-                                _p(ws), nws, _stream()), "vitm_gemm_tn")
+    _lib.check(lib.vitm_gemm_tn(_p(a), a.stride(0), _p(b), b.stride(0), _p(out), out.stride(0), _p(colsum_out),
+                                _p(None if row_scale is None else _f32(row_scale)), M, N, K, _p(ws), nws, _stream()),
+               "vitm_gemm_tn")
     return out
 
 
 def linear_dw(dy: torch.Tensor, x: torch.Tensor, M: int, N: int, K: int, out: Optional[torch.Tensor] = None,
-              bias_out: Optional[torch.Tensor] = None) -> torch.Tensor:
+              bias_out: Optional[torch.Tensor] = None, dy_scale: Optional[torch.Tensor] = None) -> torch.Tensor:
     """dW[N, K] (fp32) = dy[:, :N]^T . x[:, :K], and the bias gradient sum_m dy[m, :N] into ``bias_out`` when given.
     bf16 operands: the transposing weight-gradient GEMM (fp32 accumulators stored as fp32, the bias gradient from the
     same pass).  fp32 operands: the forward GEMM on the two transposed activations (rows padded to its K multiple) and
-    a column-sum kernel.  ``out`` (contiguous [N, K] fp32) receives dW when given."""
+    a column-sum kernel.  ``out`` (contiguous [N, K] fp32) receives dW when given.  ``dy_scale`` (N floats, bf16 path
+    only) stands for dy * dy_scale."""
     if dy.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and _tn_ok(dy) and _tn_ok(x):
-        return gemm_tn(dy, x, M, N, K, out, bias_out)
+        return gemm_tn(dy, x, M, N, K, out, bias_out, dy_scale)
+    assert dy_scale is None, "dy_scale needs the bf16 weight-gradient GEMM"
     if bias_out is not None:
         colsum(dy, M, N, out=bias_out)
     mp = round_up(M, k_multiple())

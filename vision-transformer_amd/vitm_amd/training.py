@@ -224,11 +224,26 @@ class _Grads(dict):
         return t.view(*shape) if shape else t.view(-1)
 
 
-def _linear_backward(G: _Grads, lin: nn.Linear, dy: torch.Tensor, x_in: torch.Tensor, M: int, need_dx: bool = True):
-    """Gradients of y = x W^T + b: G[weight], G[bias]; returns dx [M, >= in_features] (or None)."""
+def _linear_backward(G: _Grads, lin: nn.Linear, dy: torch.Tensor, x_in: torch.Tensor, M: int, need_dx: bool = True,
+                     dy_scale: Optional[torch.Tensor] = None, gelu_input: Optional[torch.Tensor] = None,
+                     dx_out: Optional[torch.Tensor] = None):
+    """Gradients of y = x W^T + b: G[weight], G[bias]; returns dx [M, >= in_features] (or None).  ``dy_scale`` stands
+    for dy * dy_scale (a LayerScale behind the layer); ``gelu_input`` multiplies dx by GELU'(gelu_input)."""
     N, K = lin.weight.shape
-    T.linear_dw(dy, x_in, M, N, K, out=G.buf(lin.weight, N, K), bias_out=G.buf(lin.bias) if lin.bias is not None else None)
-    return T.linear_dx(dy, lin.weight, M) if need_dx else None
+    T.linear_dw(dy, x_in, M, N, K, out=G.buf(lin.weight, N, K), bias_out=G.buf(lin.bias) if lin.bias is not None else None,
+                dy_scale=dy_scale)
+    return T.linear_dx(dy, lin.weight, M, out=dx_out, gelu_input=gelu_input, dy_scale=dy_scale) if need_dx else None
+
+
+def _scaled(dx: torch.Tensor, gamma: torch.Tensor, M: int, D: int):
+    """(dy, dy_scale) for the Linear in front of a LayerScale, given the gradient behind it: bf16 keeps dx and hands the
+    scale to the GEMMs (folded into W^T and into the rows of dW); fp32 materialises dx * gamma."""
+    if dx.dtype == torch.bfloat16:
+        return dx, gamma
+    D8 = _ops.round_up(D, 8)
+    dz = torch.empty((M, D8), dtype=dx.dtype, device=dx.device)
+    _ops.scale_channels(dx[:, :D8] if dx.shape[1] != D8 else dx, dz, M, D8, _pad8(gamma))
+    return dz, None
 
 
 def _block_backward(G: _Grads, blk: Block, s: dict, dx2: torch.Tensor, B: int, N: int) -> torch.Tensor:
@@ -240,11 +255,9 @@ def _block_backward(G: _Grads, blk: Block, s: dict, dx2: torch.Tensor, B: int, N
 
     # ---- MLP branch: x2 = x1 + g2 * z2, z2 = fc2(gelu(pre)), pre = fc1(LN2(x1))
     T.colsum(dx2, M, D, s["z2"], out=G.buf(blk.ls2.gamma))
-    dz2 = torch.empty((M, _ops.round_up(D, 8)), dtype=cd, device=dev)
-    _ops.scale_channels(dx2[:, :dz2.shape[1]] if dx2.shape[1] != dz2.shape[1] else dx2, dz2, M, _ops.round_up(D, 8), _pad8(g2))
+    dz2, sc2 = _scaled(dx2, g2, M, D)
     if cd == torch.bfloat16:      # GELU backward in the epilogue of the input-gradient GEMM
-        _linear_backward(G, mlp.linear_layer2, dz2, s["h"], M, need_dx=False)
-        dpre = T.linear_dx(dz2, mlp.linear_layer2.weight, M, gelu_input=s["pre"])
+        dpre = _linear_backward(G, mlp.linear_layer2, dz2, s["h"], M, dy_scale=sc2, gelu_input=s["pre"])
     else:
         dh = _linear_backward(G, mlp.linear_layer2, dz2, s["h"], M)
         dpre = dh                                         # in place: element-wise
@@ -258,9 +271,8 @@ def _block_backward(G: _Grads, blk: Block, s: dict, dx2: torch.Tensor, B: int, N
 
     # ---- attention branch: x1 = x + g1 * z1, z1 = proj(attn(qkv)), qkv = Wqkv LN1(x)
     T.colsum(dx1, M, D, s["z1"], out=G.buf(blk.ls1.gamma))
-    dz1 = dz2
-    _ops.scale_channels(dx1[:, :dz1.shape[1]] if dx1.shape[1] != dz1.shape[1] else dx1, dz1, M, _ops.round_up(D, 8), _pad8(g1))
-    d_o = _linear_backward(G, attn.proj, dz1, s["o"], M)
+    dz1, sc1 = _scaled(dx1, g1, M, D)
+    d_o = _linear_backward(G, attn.proj, dz1, s["o"], M, dy_scale=sc1)
     dqkv = torch.empty((M, 3 * D), dtype=cd, device=dev)
     _attention_backward(G, attn, s, d_o, dqkv, B, N, "Attention")
     dn1 = _linear_backward(G, attn.qkv, dqkv, s["n1"], M)
@@ -313,18 +325,16 @@ def _pblock_backward(G: _Grads, blk: ParallelBlock, s: dict, dx2: torch.Tensor, 
     gam = _ops.f32vec(blk.layer_scale.gamma)
     # x2 = x + gamma * z, z = fused_proj_2(cat)
     T.colsum(dx2, M, D, s["z"], out=G.buf(blk.layer_scale.gamma))
-    dz = torch.empty((M, D), dtype=cd, device=dev)
-    _ops.scale_channels(dx2[:, :D] if dx2.shape[1] != D else dx2, dz, M, D, gam)
-    dcat = _linear_backward(G, blk.fused_proj_2, dz, s["cat"], M)                 # [M, >= 2D]
+    dz, sc = _scaled(dx2, gam, M, D)
+    dcat = _linear_backward(G, blk.fused_proj_2, dz, s["cat"], M, dy_scale=sc)    # [M, >= 2D]
     # attention half: cat[:, :D] = attn.proj(o)
     d_o = _linear_backward(G, blk.attn.proj, dcat[:, :D], s["o"], M)
     # MLP half: cat[:, D:2D] = out_proj(gelu(pre))
     # gradient of the fused first projection's output, [q | k | v | hidden] side by side like its weight rows
     d1 = _buf(M, 3 * D + hid, dev, cd)
     if cd == torch.bfloat16:      # GELU backward in the epilogue of the input-gradient GEMM, written in place
-        _linear_backward(G, blk.mlp.out_proj, dcat[:, D:2 * D], s["h"], M, need_dx=False)
-        T.linear_dx(dcat[:, D:2 * D], blk.mlp.out_proj.weight, M, out=d1[:, 3 * D:3 * D + _ops.round_up(hid, 8)],
-                    gelu_input=s["pre"])
+        _linear_backward(G, blk.mlp.out_proj, dcat[:, D:2 * D], s["h"], M, gelu_input=s["pre"],
+                         dx_out=d1[:, 3 * D:3 * D + _ops.round_up(hid, 8)])
     else:
         dh = _linear_backward(G, blk.mlp.out_proj, dcat[:, D:2 * D], s["h"], M)
         T.gelu_bwd(s["pre"], dh, d1[:, 3 * D:3 * D + hid], M, hid)
