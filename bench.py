@@ -3,9 +3,15 @@
     python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--config vit_b16]
 
 A "step" is one forward of the hot path (patch embedding -> 12 blocks -> final norm -> head) over one batch
-of synthetic images already resident in HBM.  With N > 1 (launched by torch.distributed.run, one rank per
-GPU) every rank runs its own replica on its own batch shard -- inference needs no collective -- and the
-reported value is all images of all ranks divided by the slowest rank's time (weak scaling).
+of synthetic images already resident in HBM.  With N > 1 every rank (one per GPU) runs its own replica on its
+own batch shard -- inference needs no collective -- and the reported value is all images of all ranks divided
+by the slowest rank's time (weak scaling).  ``python bench.py --gpus N`` outside a torch.distributed.run launch
+starts the N ranks itself (a child ``python -m torch.distributed.run``, before this process touches a GPU) and
+relays rank 0's line and the exit code; a launch whose rank count differs from --gpus exits non-zero.
+
+Timing: W warm-up steps (continued until the clocks have had >= 2 s of back-to-back forwards), then rounds of
+EXACTLY K steps, each bracketed by barrier + synchronize, until >= 1 s has been timed; the line reports the
+median round (``rounds`` lists how many, with the fastest and slowest).
 
 Rank 0 prints ONE JSON line.  ``roofline`` prices the dominant kernel, the LayerNorm-folded fc1 GEMM with the
 GELU epilogue (M = B*197, N = 3072, K = 768), by its algorithmic FLOPs per launch over its average launch
@@ -44,6 +50,23 @@ def measured_traffic(config, batch):
             t = json.load(f)
         if t.get("config") == config and t.get("batch_per_gpu") == batch:
             return t.get("hbm_bytes_per_launch")
+    except (OSError, ValueError):
+        pass
+    return None
+
+
+ALGO_BYTES_PER_IMAGE = {"vit_b16": 79.9e6, "vit_s16": 39.9e6, "vit_b16_384": 234e6}   # per-op-fused bf16 intermediates
+FORWARD_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r2_forward_traffic.json")
+
+
+def measured_forward_traffic(config, batch):
+    """HBM bytes per image over the whole forward (sum over kernels of PMC bytes x calls) from the committed
+    rocprofv3 --pmc passes; None when the committed measurement is for another workload."""
+    try:
+        with open(FORWARD_TRAFFIC_FILE) as f:
+            t = json.load(f)
+        if t.get("config") == config and t.get("batch_per_gpu") == batch:
+            return t.get("hbm_bytes_per_image")
     except (OSError, ValueError):
         pass
     return None
@@ -150,7 +173,8 @@ def train_bench(args, world, rank, dist, dev):
         peak = 2500.0 if bf16 else 157.0
         print(json.dumps({
             "metric": f"images/sec, {args.config} {'bf16 mixed-precision' if bf16 else 'fp32'} training step", "value": round(value, 1), "unit": "images/sec",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "n_gpus": world, "ranks_seen": dist.get_world_size() if dist is not None else 1,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if bf16 else "f32", "data": "synthetic",
             "config": {"workload": f"{args.config}: forward + cross-entropy + backward + gradient all-reduce + clip + AdamW",
                        "batch_per_gpu": args.batch, "global_batch": args.batch * world,
@@ -164,6 +188,77 @@ def train_bench(args, world, rank, dist, dev):
         dist.destroy_process_group()
 
 
+def self_launch(n: int, argv) -> int:
+    """Start n ranks of this script under torch.distributed.run (child process; nothing here has touched a GPU),
+    relay rank 0's output, return the child's exit code.  The reference's own multi-process entry spawns its
+    ranks the same way (vitm/models/sv22b.py:260-315)."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+def gather_floats(value: float, dist, dev):
+    """Every rank's scalar, on every rank (a list of world-size floats)."""
+    if dist is None:
+        return [float(value)]
+    t = torch.tensor([value], dtype=torch.float64, device=dev)
+    out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [float(o.item()) for o in out]
+
+
+def hipblaslt_calibration(dev, n=4096, iters=20):
+    """TFLOP/s of torch.matmul (hipBLASLt) on an n^3 bf16 problem, random data, on this box: the practical MFMA
+    ceiling next to which the roofline fraction is also reported.  Outside the timed region."""
+    a = torch.randn(n, n, device=dev).to(torch.bfloat16)
+    b = torch.randn(n, n, device=dev).to(torch.bfloat16)
+    for _ in range(5):
+        a @ b
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        a @ b
+    e1.record()
+    torch.cuda.synchronize()
+    return 2.0 * n ** 3 / (e0.elapsed_time(e1) / iters * 1e-3) / 1e12
+
+
+def selftest_launch(args, world, rank, dist):
+    """Launcher rehearsal without a GPU (gloo): the same rank start-up, barriers, max-over-ranks and JSON path
+    around a no-op step.  Used by the CPU tests."""
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+    for _ in range(args.warmup):
+        time.sleep(0.001)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.001)
+    barrier()
+    el = time.perf_counter() - t0
+    per_rank = gather_floats(args.batch * args.steps / el, dist, None)
+    from vitm_amd.sharding import max_over_ranks
+    el = max_over_ranks(el, dist, None)
+    ranks_seen = dist.get_world_size() if dist is not None else 1
+    if rank == 0:
+        print(json.dumps({"metric": "launcher self-test (no GPU work)", "value": round(world * args.batch * args.steps / el, 1),
+                          "unit": "items/sec", "n_gpus": world, "ranks_seen": ranks_seen, "steps": args.steps,
+                          "warmup": args.warmup, "per_rank": [round(v, 1) for v in per_rank]}), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0 if ranks_seen == args.gpus else 3
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -172,23 +267,38 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="images per GPU per step")
     ap.add_argument("--config", default="vit_b16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--warm-seconds", type=float, default=2.0, help="minimum warm-up time before the timed region")
+    ap.add_argument("--min-timed-seconds", type=float, default=1.0, help="repeat the K-step round until this much is timed")
     ap.add_argument("--graph", action="store_true", help="replay the forward from a HIP graph (same kernels, one host call)")
     ap.add_argument("--mode", default="forward", choices=["forward", "train"],
                     help="train: one training step per step (forward, loss, backward, all-reduce, clip, AdamW)")
     ap.add_argument("--dtype", default=None, choices=["bf16", "f32"],
                     help="training arithmetic (default f32, the reference's); the forward benchmark is bf16")
+    ap.add_argument("--selftest-launch", action="store_true",
+                    help="rehearse the multi-rank launch on CPU (gloo) around a no-op step; no GPU is touched")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # not under a launcher: start the ranks ourselves, before anything here initialises a GPU
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: refusing to report an {args.gpus}-GPU number "
+                         f"from {world} rank(s)")
     dist = None
+    if args.selftest_launch:
+        if world > 1:
+            import torch.distributed as dist
+            dist.init_process_group(backend="gloo")
+        sys.exit(selftest_launch(args, world, rank, dist))
     if world > 1:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit(f"process group has {dist.get_world_size()} ranks, --gpus {args.gpus}")
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
@@ -214,19 +324,40 @@ def main():
     if args.graph:
         from vitm_amd import GraphedForward
         fwd = GraphedForward(model, x)
+    from vitm_amd.sharding import max_over_ranks
     with torch.no_grad():
         for _ in range(args.warmup):
             fwd(x)
-        barrier()
+        torch.cuda.synchronize()
+        # keep warming until the chip has seen WARM_S seconds of back-to-back forwards (its clock settles over
+        # seconds under an MFMA-dense load); the count is agreed across ranks
         t0 = time.perf_counter()
-        for _ in range(args.steps):
-            out = fwd(x)
-        barrier()
-        elapsed = time.perf_counter() - t0
+        for _ in range(3):
+            fwd(x)
+        torch.cuda.synchronize()
+        per_fwd = max_over_ranks((time.perf_counter() - t0) / 3, dist, dev)
+        extra_warm = max(0, min(2000, int(args.warm_seconds / per_fwd) - 3))
+        for _ in range(extra_warm):
+            fwd(x)
+        # rounds of exactly --steps forwards, each bracketed by barrier + synchronize, until >= --min-timed-seconds
+        n_rounds = max(1, min(200, int(args.min_timed_seconds / (per_fwd * args.steps) + 0.999)))
+        rounds = []
+        for _ in range(n_rounds):
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                out = fwd(x)
+            barrier()
+            rounds.append(time.perf_counter() - t0)
     assert torch.isfinite(out.float()).all()
 
-    from vitm_amd.sharding import max_over_ranks
-    elapsed = max_over_ranks(elapsed, dist, dev)
+    # per round the slowest rank's time; the line reports the median round
+    rounds = [max_over_ranks(r, dist, dev) for r in rounds]
+    order = sorted(range(len(rounds)), key=lambda i: rounds[i])
+    med = order[len(order) // 2]
+    elapsed = rounds[med]
+    ranks_seen = dist.get_world_size() if dist is not None else 1
+    per_rank = gather_floats(args.batch * args.steps / elapsed, dist, dev)   # each rank at the median round's clock
 
     line = None
     if rank == 0:
@@ -239,8 +370,8 @@ def main():
         line = {
             "metric": "images/sec, ViT-B/16 224px bf16 classification forward" if args.config == "vit_b16"
                       else f"images/sec, {args.config} bf16 classification forward",
-            "value": round(value, 1), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(ms_step, 3), "higher_is_better": True,
+            "value": round(value, 1), "unit": "images/sec", "n_gpus": world, "ranks_seen": ranks_seen,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"{args.config}: image {cfg['image_size']}, patch {cfg['patch_size']}, "
                                    f"{shp['tokens']} tokens, dim {shp['embed_dim']}, depth {shp['depth']}, "
@@ -257,7 +388,20 @@ def main():
                          "launches_timed": n_launch},
             "whole_forward": {"tflops_per_gpu": round(model_tflops, 1),
                               "frac_of_bf16_peak": round(model_tflops / PEAK_BF16_TFLOPS, 4)},
+            "rounds": {"timed": len(rounds), "steps_each": args.steps, "reported": "median",
+                       "ms_per_step_min": round(min(rounds) / args.steps * 1e3, 3),
+                       "ms_per_step_max": round(max(rounds) / args.steps * 1e3, 3),
+                       "warmup_forwards": args.warmup + 3 + extra_warm},
+            "per_rank_images_per_sec": [round(v, 1) for v in per_rank],
         }
+        blaslt = hipblaslt_calibration(dev)
+        line["roofline"]["hipblaslt_4096_tflops"] = round(blaslt, 1)
+        line["roofline"]["frac_of_hipblaslt_4096"] = round(fc1_tflops / blaslt, 4)
+        line["whole_forward"]["frac_of_hipblaslt_4096"] = round(model_tflops / blaslt, 4)
+        wf = measured_forward_traffic(args.config, args.batch)
+        if wf is not None:
+            line["whole_forward"]["hbm_bytes_per_image_measured"] = wf
+            line["whole_forward"]["hbm_bytes_per_image_algorithmic"] = ALGO_BYTES_PER_IMAGE.get(args.config)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, sd)
     if dist is not None:

@@ -157,3 +157,61 @@ def test_bucketed_gradient_allreduce_two_ranks():
     for p in procs:
         p.join(timeout=60)
     assert res == [(0, True), (1, True)]
+
+
+def _runner_worker(rank, world, port, q):
+    for p in (ROOT, os.path.join(ROOT, "vision-transformer_amd"), os.path.join(ROOT, "tests", "golden")):
+        sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from vitm_amd.sharding import ShardedInference
+        torch.manual_seed(0)
+        model = torch.nn.Sequential(torch.nn.Flatten(), torch.nn.Linear(12, 5))     # a stand-in replica
+        x = torch.randn(7, 3, 2, 2)
+        runner = ShardedInference(model, dist, micro_batch=2)
+        local, (s, e) = runner(x)
+        assert local.shape[0] == e - s
+        via_fn, b2 = ShardedInference(model, dist)(lambda a, b: x[a:b], n_items=7)
+        assert b2 == (s, e) and torch.allclose(via_fn, local, atol=1e-6)   # CPU GEMM blocking differs with the row count
+        full = runner.gather(local)
+        if rank == 0:
+            q.put(bool(full.shape[0] == 7 and torch.allclose(full, model(x), atol=1e-6)))
+        else:
+            assert full is None
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_inference_runner_two_ranks():
+    """ShardedInference: contiguous chunks, micro-batching, callable loaders and the optional gather."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_runner_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    ok = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert ok
+
+
+def test_bench_self_launches_its_ranks():
+    """`python bench.py --gpus 2` outside a launcher starts two ranks itself and reports them; a rank count that
+    differs from --gpus is refused with a non-zero exit.  (--selftest-launch: gloo, no GPU work.)"""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--selftest-launch", "--steps", "3",
+                        "--warmup", "1"], capture_output=True, text=True, timeout=240, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["ranks_seen"] == 2 and len(out["per_rank"]) == 2
+    env["WORLD_SIZE"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--selftest-launch"],
+                       capture_output=True, text=True, timeout=120, env=env)
+    assert r.returncode != 0 and "refusing" in r.stderr

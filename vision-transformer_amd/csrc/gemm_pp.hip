@@ -58,7 +58,7 @@
   do {                                                                                             \
     unsigned long long t__;                                                                        \
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__)::"memory");                    \
-    if (tid == 0 && it < 12 && p.resid) ((unsigned long long*)p.resid)[((size_t)blockIdx.x * 12 + it) * 4 + (k)] = t__; \
+    if (!SLICE && tid == 0 && it < 12 && p.resid) ((unsigned long long*)p.resid)[((size_t)blockIdx.x * 12 + it) * 8 + (k)] = t__; \
   } while (0)
 #else
 #define STAMP(k) do {} while (0)
@@ -329,7 +329,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_pp_kernel(const GemmArgs p) {
 
     STAMP(0);
 #ifdef PP_STAMP
-    if (tid == 0 && it < 12 && p.resid) ((unsigned long long*)p.resid)[((size_t)blockIdx.x * 12 + it) * 4 + 3] = __builtin_amdgcn_s_memrealtime();
+    if (!SLICE && tid == 0 && it < 12 && p.resid) ((unsigned long long*)p.resid)[((size_t)blockIdx.x * 12 + it) * 8 + 3] = __builtin_amdgcn_s_memrealtime();
 #endif
     if (grp == 1) seg_barrier();   // group 0's first LOAD of the tile
     for (int t = 0; t < nk; ++t) {
@@ -353,6 +353,11 @@ __global__ __launch_bounds__(NT, 2) void gemm_pp_kernel(const GemmArgs p) {
       seg_barrier();
       ca = ca == NA - 1 ? 0 : ca + 1;
       cw ^= 1;
+#ifdef PP_STAMP
+      if (t == 0) STAMP(4);
+      if (t == 1) STAMP(5);
+      if (t == 2) STAMP(6);
+#endif
     }
     if (grp == 0) seg_barrier();   // group 1's last COMPUTE of the tile
     STAMP(1);
@@ -534,7 +539,10 @@ int launch(const GemmArgs& a, hipStream_t st) {
   }
   const int ncu = vitm_cu_count();
   const int64_t tiles = (int64_t)b.tilesM * b.tilesN;
-  const int grid = (int)(tiles < ncu ? tiles : ncu);   // one persistent workgroup per CU
+  int grid = (int)(tiles < ncu ? tiles : ncu);   // one persistent workgroup per CU
+#ifdef PP_STAMP
+  if (const char* e = getenv("VITM_PP_GRID")) grid = atoi(e);   // diagnostic: fewer workgroups than CUs
+#endif
   b.ncu = grid;
   // Share the leftover tiles of a partly filled last round when that round would be less than ~70 % full and
   // there is at least one whole round to amortise the second launch over.

@@ -405,7 +405,7 @@ class VisionTransformer(nn.Module):
         npre = layernorm_params(self.norm_pre, "VisionTransformer.norm_pre")
         f = _ops.f32vec
         _ops.embed_finalize(
-            x2d, B, N, D, f(self.class_token.reshape(-1)) if has_cls else None, f(self.pos_embed.reshape(N, D)),
+            x2d, B, N, D, f(self.class_token).reshape(-1) if has_cls else None, f(self.pos_embed).reshape(N, D),
             f(en[0]) if en else None, f(en[1]) if en else None, en[2] if en else 0.0,
             f(npre[0]) if npre else None, f(npre[1]) if npre else None, npre[2] if npre else 0.0)
         return x2d, B, N, D
