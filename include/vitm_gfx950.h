@@ -97,6 +97,25 @@ int vitm_gemm(const void* A, int64_t lda, const void* Wp, int64_t ldw, void* out
               vitm_stream_t stream);
 
 /*
+ * vitm_gemm (bf16 output, row_group 0) on the 256x256-tile route with the LayerNorm row statistics carried from
+ * the GEMM that writes the residual stream to the GEMM that normalises it, instead of a vitm_ln_stats pass over
+ * the stream in between:
+ *  - stats_out != NULL (VITM_EPI_RESIDUAL, N <= VITM_STATS_PARTS * 256): besides `out`, the epilogue writes for every
+ *    row m and 256-column tile t the raw moments of that tile's output values of the row,
+ *    stats_out[(m * VITM_STATS_PARTS + t) * 2 + {0, 1}] = (sum, sum of squares); slots t >= ceil(N / 256) are
+ *    not written and must be zero (clear the [M][VITM_STATS_PARTS][2] buffer once).
+ *  - stats_partial != 0 (VITM_EPI_LN*): `stats` is such a buffer; the epilogue sums the slots and forms
+ *    mean = sum / ln_dim, rstd = 1 / sqrt(sumsq / ln_dim - mean^2 + ln_eps) itself.
+ * Fails with VITM_EINVAL when the shape does not take the 256x256-tile route (ask vitm_gemm_uses_big_tile first).
+ * Replaces the statistics half of the two nn.LayerNorm calls of Block.forward (models.py:189,196,209-210).
+ */
+#define VITM_STATS_PARTS 4
+int vitm_gemm_stats(const void* A, int64_t lda, const void* Wp, int64_t ldw, void* out, int64_t ldo, int M, int N,
+                    int K, int epilogue, const float* stats, const float* s, const float* c, const float* g,
+                    const void* resid, int64_t ldr, float* stats_out, int stats_partial, int ln_dim, float ln_eps,
+                    vitm_stream_t stream);
+
+/*
  * Patch embedding as an im2col-fused GEMM: tokens[b, 1 + py*gw + px, :] =
  *   sum_{c,ky,kx} img[b,c,py*ph+ky,px*pw+kx] * Wp[:, (c,ky,kx)] + c[:]
  * img is NCHW (bf16 or f32) contiguous, Wp is the packed (D, kpad) projection weight.  With

@@ -91,6 +91,45 @@ def test_gemm_big_tile_kernel(ops, M, N, K, epi):
         _close(out, ref, rel=1e-4 if epi == "bias_f32" else 1e-2, what=f"big {epi}")
 
 
+@pytest.mark.parametrize("M,N,K,Kn", [(50432, 768, 768, 2304), (50432, 768, 3072, 3072), (33000, 1024, 256, 1024),
+                                      (40000, 384, 128, 1152), (66000, 512, 256, 512), (16400, 520, 64, 1040)])
+def test_gemm_carried_layernorm_stats(ops, M, N, K, Kn):
+    """The RESIDUAL epilogue's row moments (vitm_gemm_stats stats_out) against float64 moments of the stream it wrote,
+    and an LN-folded GEMM fed with them (stats_partial) against the same GEMM fed by vitm_ln_stats.  Shapes cover
+    1-4 column tiles, a ragged last column tile (N = 384, 520), ragged M and leftover tiles shared 2, 3 and 4 ways."""
+    A = _bf(_rand(M, K, seed=50))
+    W, b = _rand(N, K, seed=51, scale=K ** -0.5), _rand(N, seed=52, scale=0.2)
+    gamma = 1.0 + 0.1 * _rand(N, seed=53)
+    x = _bf(_rand(M, N, seed=54) * 1.5 + 0.7)          # mean well away from 0: the raw moments must cope
+    pk = ops.pack_linear(W, b, out_scale=gamma)
+    assert ops.uses_big_tile(M, pk)
+    carried = ops.new_carried_stats(M, DEV)
+    carried[:, : (N + 255) // 256] = float("nan")      # every slot of a written tile must be overwritten
+    ops.gemm(A, pk, x, ops.EPI_RESIDUAL, M, resid=x, stats_out=carried)
+    xs = x.double()
+    tot = carried.double().sum(1)
+    assert torch.isfinite(tot).all()
+    mean, var = tot[:, 0] / N, tot[:, 1] / N - (tot[:, 0] / N) ** 2
+    rmean, rvar = xs.mean(1), xs.var(1, unbiased=False)
+    # the moments are those of the fp32 values before their rounding to bf16: the mean moves by << 1e-3 sigma
+    assert ((mean - rmean).abs() / rvar.sqrt()).max().item() < 1e-3
+    assert ((var - rvar).abs() / rvar).max().item() < 2e-3
+    # consumer: LayerNorm over the N columns of x folded into the next GEMM
+    lw, lb = 1.0 + 0.1 * _rand(N, seed=55), 0.1 * _rand(N, seed=56)
+    W2, b2 = _rand(Kn, N, seed=57, scale=N ** -0.5), _rand(Kn, seed=58, scale=0.2)
+    pk2 = ops.pack_linear(W2, b2, lw, lb)
+    if pk2.kpad != N:
+        return   # N = 520 has K padding in the consumer; the moments above are what this case is for
+    assert ops.uses_big_tile(M, pk2)
+    out_a = torch.full((M, Kn), float("nan"), dtype=torch.bfloat16, device=DEV)
+    out_b = torch.full((M, Kn), float("nan"), dtype=torch.bfloat16, device=DEV)
+    ops.gemm(x, pk2, out_a, ops.EPI_LN, M, stats=carried, stats_partial=True, ln_eps=1e-5)
+    ops.gemm(x, pk2, out_b, ops.EPI_LN, M, stats=ops.ln_stats(x, M, N, 1e-5))
+    ref = torch.nn.functional.layer_norm(x.float(), (N,), lw, lb, 1e-5) @ W2.t() + b2
+    _close(out_a, ref, rel=1.5e-2, what="LN GEMM on carried moments")
+    _close(out_a, out_b, rel=8e-3, what="carried moments vs vitm_ln_stats")
+
+
 def test_gemm_identity_asymmetric(ops):
     """A = I against an asymmetric W catches a transposed / permuted fragment map exactly."""
     K = N = 128

@@ -247,16 +247,18 @@ int dispatch(const GemmArgs& a, int epi, int out_f32, hipStream_t st) {
 }
 
 inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+constexpr int BN_BIG = 256;   // column tile of the big-tile kernel (one statistics slot per tile)
 
 }  // namespace
 
 extern "C" int vitm_gemm_k_multiple(void) { return BK; }
 extern "C" int vitm_gemm_uses_big_tile(int M, int N, int K) { return vitm_gemm_pp_wanted(M, N, K) ? 1 : 0; }
 
-extern "C" int vitm_gemm(const void* A, int64_t lda, const void* Wp, int64_t ldw, void* out, int64_t ldo,
-                         int out_dtype, int M, int N, int K, int epilogue, const float* stats,
-                         const float* s, const float* c, const float* g, const void* resid,
-                         int64_t ldr, int row_group, vitm_stream_t stream) {
+static int gemm_impl(const void* A, int64_t lda, const void* Wp, int64_t ldw, void* out, int64_t ldo,
+                     int out_dtype, int M, int N, int K, int epilogue, const float* stats,
+                     const float* s, const float* c, const float* g, const void* resid,
+                     int64_t ldr, int row_group, float* stats_out, int stats_partial, int ln_dim, float ln_eps,
+                     vitm_stream_t stream) {
   VITM_REQUIRE(A && Wp && out && c, "vitm_gemm: null A/Wp/out/c pointer");
   VITM_REQUIRE(M > 0 && N > 0 && K > 0, "vitm_gemm: M, N, K must be positive (got %d, %d, %d)", M, N, K);
   VITM_REQUIRE(K % BK == 0, "vitm_gemm: K=%d must be a multiple of %d (pad the packed weight and A)", K, BK);
@@ -273,13 +275,39 @@ extern "C" int vitm_gemm(const void* A, int64_t lda, const void* Wp, int64_t ldw
   VITM_REQUIRE(epilogue != VITM_EPI_DGELU || (resid && aligned16(resid) && ldr >= N && ldr % 8 == 0 && out_dtype == VITM_BF16),
                "vitm_gemm: DGELU epilogue needs resid (the GELU input, ldr >= N, multiple of 8) and bf16 output");
   VITM_REQUIRE(row_group >= 0, "vitm_gemm: row_group must be >= 0");
+  const bool big = row_group == 0 && out_dtype == VITM_BF16 && vitm_gemm_pp_wanted(M, N, K);
+  if (stats_out != nullptr || stats_partial) {
+    VITM_REQUIRE(big, "vitm_gemm_stats: carried LayerNorm statistics need the 256x256-tile route (vitm_gemm_uses_big_tile)");
+    VITM_REQUIRE(stats_out == nullptr || (epilogue == VITM_EPI_RESIDUAL && N <= VITM_STATS_PARTS * BN_BIG && aligned16(stats_out)),
+                 "vitm_gemm_stats: stats_out needs the RESIDUAL epilogue, N <= %d and a 16-byte aligned buffer", VITM_STATS_PARTS * BN_BIG);
+    VITM_REQUIRE(!stats_partial || (ln && aligned16(stats) && ln_dim > 0 && ln_eps > 0.f),
+                 "vitm_gemm_stats: partial statistics need an LN epilogue, a 16-byte aligned stats buffer, ln_dim and ln_eps");
+  }
   GemmArgs a{};
+  a.stats_out = stats_out; a.stats_partial = stats_partial ? 1 : 0;
+  a.ln_inv_dim = ln_dim > 0 ? 1.0f / (float)ln_dim : 0.f; a.ln_eps = ln_eps;
   a.A = (const bf16_t*)A; a.lda = lda; a.W = (const bf16_t*)Wp; a.ldw = ldw;
   a.out = out; a.ldo = ldo; a.stats = stats; a.s = s; a.c = c; a.g = g;
   a.resid = (const bf16_t*)resid; a.ldr = ldr;
   a.M = M; a.N = N; a.K = K; a.tilesN = (N + BN - 1) / BN; a.row_group = row_group;
-  if (row_group == 0 && out_dtype == VITM_BF16 && vitm_gemm_pp_wanted(M, N, K)) return vitm_gemm_pp_launch(a, epilogue, (hipStream_t)stream);
+  if (big) return vitm_gemm_pp_launch(a, epilogue, (hipStream_t)stream);
   return dispatch<A_DIRECT>(a, epilogue, out_dtype == VITM_F32, (hipStream_t)stream);
+}
+
+extern "C" int vitm_gemm(const void* A, int64_t lda, const void* Wp, int64_t ldw, void* out, int64_t ldo,
+                         int out_dtype, int M, int N, int K, int epilogue, const float* stats,
+                         const float* s, const float* c, const float* g, const void* resid,
+                         int64_t ldr, int row_group, vitm_stream_t stream) {
+  return gemm_impl(A, lda, Wp, ldw, out, ldo, out_dtype, M, N, K, epilogue, stats, s, c, g, resid, ldr, row_group,
+                   nullptr, 0, 0, 0.f, stream);
+}
+
+extern "C" int vitm_gemm_stats(const void* A, int64_t lda, const void* Wp, int64_t ldw, void* out, int64_t ldo,
+                               int M, int N, int K, int epilogue, const float* stats, const float* s,
+                               const float* c, const float* g, const void* resid, int64_t ldr,
+                               float* stats_out, int stats_partial, int ln_dim, float ln_eps, vitm_stream_t stream) {
+  return gemm_impl(A, lda, Wp, ldw, out, ldo, VITM_BF16, M, N, K, epilogue, stats, s, c, g, resid, ldr, 0,
+                   stats_out, stats_partial, ln_dim, ln_eps, stream);
 }
 
 extern "C" int vitm_patch_embed(const void* img, int img_dtype, int B, int C, int H, int W, int ph, int pw,

@@ -20,6 +20,13 @@ struct GemmArgs {
   int M, N, K, tilesM, tilesN, row_group;
   int ncu, share, S;   // big-tile kernel: persistent workgroups, leftover tiles shared (0/1) by S workgroups each
   int band;            // big-tile kernel: N-tiles per column band of the tile order (tilesN: plain row-major)
+  // LayerNorm statistics carried between GEMMs (big-tile kernel).  stats_out: the RESIDUAL epilogue also writes, per
+  // output row m and 256-column tile t, the raw moments (sum, sum of squares) of that tile's values of the row to
+  // stats_out[(m * VITM_STATS_PARTS + t) * 2].  stats_partial: the LN epilogues read `stats` in that layout (all
+  // VITM_STATS_PARTS slots are summed; unused ones must be zero) and form mean / rstd over ln_dim values themselves.
+  float* stats_out;
+  int stats_partial;
+  float ln_inv_dim, ln_eps;
   // im2col source (patch embedding)
   const void* img;
   int C, H, Wd, ph, pw, gw, npatch, kreal, vec;

@@ -86,6 +86,15 @@ __device__ __forceinline__ void swap16(float& a, float& b) {
   asm volatile("v_nop\n\tv_nop\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
 }
 
+// v_permlane32_swap: lanes 32-63 of `a` trade places with lanes 0-31 of `b`; afterwards a lane of the lower half holds
+// (its own a, the a of lane+32) and a lane of the upper half (the b of lane-32, its own b).
+__device__ __forceinline__ void swap32(float& a, float& b) {
+  asm volatile("v_nop\n\tv_nop\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ float ror8(float x) {   // the value of lane ^ 8
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0u, __builtin_bit_cast(unsigned, x), 0x128, 0xf, 0xf, false));
+}
+
 // Lanes l and l^8 (output rows r and r+8 of a 16-row accumulator tile) trade 16-byte chunks so that one store
 // instruction covers 8 rows x 128 contiguous bytes (whole cache lines) instead of 16 rows x 64 bytes.  In: x0 / x1
 // = this lane's row, columns [c, c+8) / [c+32, c+40).  Out: x0 goes to row (r&7) and x1 to row 8+(r&7), both at
@@ -147,7 +156,8 @@ __host__ __device__ inline Deal deal_tiles(int T, int nwg, int xg, bool share, i
 
 // SLICE = false: NBLK = 8, whole tiles (p.share: the leftover tiles are left to the SLICE launch).
 // SLICE = true:  one slice of NBLK 16-row blocks (of both wave groups) of one leftover tile per workgroup.
-template <int EPI, int NBLK, bool SLICE>
+// STATS (RESIDUAL epilogue only): also write the per-row raw moments of this tile's output values (p.stats_out).
+template <int EPI, int NBLK, bool SLICE, bool STATS = false>
 __global__ __launch_bounds__(NT, 2) void gemm_pp_kernel(const GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -387,7 +397,15 @@ __global__ __launch_bounds__(NT, 2) void gemm_pp_kernel(const GemmArgs p) {
       for (int i = 0; i < NBLK; ++i) {
         int m = mrow + 16 * i;
         m = m < p.M ? m : p.M - 1;
-        st[i] = *(const float2*)(p.stats + 2 * (int64_t)m);
+        if (!p.stats_partial) {
+          st[i] = *(const float2*)(p.stats + 2 * (int64_t)m);
+        } else {   // raw moments per 256-column tile of the producing GEMM: combine, then mean and rstd
+          const float4 u = *(const float4*)(p.stats + 2 * VITM_STATS_PARTS * (int64_t)m);
+          const float4 w = *(const float4*)(p.stats + 2 * VITM_STATS_PARTS * (int64_t)m + 4);
+          const float mean = ((u.x + u.z) + (w.x + w.z)) * p.ln_inv_dim;
+          const float var = fmaf(-mean, mean, ((u.y + u.w) + (w.y + w.w)) * p.ln_inv_dim);
+          st[i] = make_float2(mean, __builtin_amdgcn_rsqf(fmaxf(var, 0.f) + p.ln_eps));
+        }
       }
     }
     const bool stores_on = (PP_ABLATE & 4) == 0;
@@ -436,6 +454,11 @@ __global__ __launch_bounds__(NT, 2) void gemm_pp_kernel(const GemmArgs p) {
       // residual values of a half in registers before its first store.  DGELU uses the same layout with
       // out = acc * gelu'(resid).
       constexpr int I4 = NBLK < 4 ? NBLK : 4, IH = NBLK / I4;
+      float rs[8][2], rq[8][2];   // STATS: moments of this lane's 8 values of rows (16 i + 8 h + (lane & 7))
+      if (STATS) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) rs[i][0] = rs[i][1] = rq[i][0] = rq[i][1] = 0.f;
+      }
 #pragma unroll
       for (int ih = 0; ih < IH; ++ih) {
         uint4 rres[I4][2];   // residual in store layout: [.][0] row (r&7), [.][1] row 8 + (r&7), columns nst .. +7
@@ -493,14 +516,27 @@ __global__ __launch_bounds__(NT, 2) void gemm_pp_kernel(const GemmArgs p) {
               }
               o = make_uint4(ow[0], ow[1], ow[2], ow[3]);
             } else {
-            o.x = pack_bf2(__builtin_bit_cast(float, rv.x << 16) + __builtin_bit_cast(float, l4[0]),
-                           __builtin_bit_cast(float, rv.x & 0xffff0000u) + __builtin_bit_cast(float, l4[1]));
-            o.y = pack_bf2(__builtin_bit_cast(float, rv.y << 16) + __builtin_bit_cast(float, l4[2]),
-                           __builtin_bit_cast(float, rv.y & 0xffff0000u) + __builtin_bit_cast(float, l4[3]));
-            o.z = pack_bf2(__builtin_bit_cast(float, rv.z << 16) + __builtin_bit_cast(float, h4[0]),
-                           __builtin_bit_cast(float, rv.z & 0xffff0000u) + __builtin_bit_cast(float, h4[1]));
-            o.w = pack_bf2(__builtin_bit_cast(float, rv.w << 16) + __builtin_bit_cast(float, h4[2]),
-                           __builtin_bit_cast(float, rv.w & 0xffff0000u) + __builtin_bit_cast(float, h4[3]));
+              const f32x2_t f0 = (f32x2_t){__builtin_bit_cast(float, rv.x << 16), __builtin_bit_cast(float, rv.x & 0xffff0000u)} +
+                                 (f32x2_t){__builtin_bit_cast(float, l4[0]), __builtin_bit_cast(float, l4[1])};
+              const f32x2_t f1 = (f32x2_t){__builtin_bit_cast(float, rv.y << 16), __builtin_bit_cast(float, rv.y & 0xffff0000u)} +
+                                 (f32x2_t){__builtin_bit_cast(float, l4[2]), __builtin_bit_cast(float, l4[3])};
+              const f32x2_t f2 = (f32x2_t){__builtin_bit_cast(float, rv.z << 16), __builtin_bit_cast(float, rv.z & 0xffff0000u)} +
+                                 (f32x2_t){__builtin_bit_cast(float, h4[0]), __builtin_bit_cast(float, h4[1])};
+              const f32x2_t f3 = (f32x2_t){__builtin_bit_cast(float, rv.w << 16), __builtin_bit_cast(float, rv.w & 0xffff0000u)} +
+                                 (f32x2_t){__builtin_bit_cast(float, h4[2]), __builtin_bit_cast(float, h4[3])};
+              o.x = pack_bf2(f0.x, f0.y);
+              o.y = pack_bf2(f1.x, f1.y);
+              o.z = pack_bf2(f2.x, f2.y);
+              o.w = pack_bf2(f3.x, f3.y);
+              if (STATS) {
+                // moments of the fp32 values before the bf16 rounding (the rounding moves the mean by ~1e-4 of the
+                // row's standard deviation and the variance by ~1e-5 of itself); columns past N count as nothing
+                const f32x2_t sp = (f0 + f1) + (f2 + f3);
+                const f32x2_t qp = f0 * f0 + f1 * f1 + (f2 * f2 + f3 * f3);
+                const bool colok = nst < p.N;
+                rs[i][h] = colok ? sp.x + sp.y : 0.f;
+                rq[i][h] = colok ? qp.x + qp.y : 0.f;
+              }
             }
             const int m = mst + 16 * i + 8 * h;
             if (stores_on && m < p.M && nst < p.N && (!SLICE || (i0 + i >= is0 && i0 + i < is1)))
@@ -508,14 +544,58 @@ __global__ __launch_bounds__(NT, 2) void gemm_pp_kernel(const GemmArgs p) {
           }
         }
       }
+      if (STATS) {
+        // Sum each row's moments over the 8 lanes that hold its 64 columns (lane bits 3, 4, 5) with a halving
+        // exchange: at every step a lane gives away half of its rows and completes the other half.  Afterwards
+        // lane l holds rows 16 i + 8 h + (l & 7), i = 4 j + 2 (l >> 5 & 1) + (l >> 4 & 1), h = l >> 3 & 1, j = 0, 1.
+        float as[8], aq[8], bs[4], bq[4], cs[2], cq2[2];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          as[i] = (hi8 ? rs[i][1] : rs[i][0]) + ror8(hi8 ? rs[i][0] : rs[i][1]);
+          aq[i] = (hi8 ? rq[i][1] : rq[i][0]) + ror8(hi8 ? rq[i][0] : rq[i][1]);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          swap16(as[2 * k], as[2 * k + 1]);
+          swap16(aq[2 * k], aq[2 * k + 1]);
+          bs[k] = as[2 * k] + as[2 * k + 1];
+          bq[k] = aq[2 * k] + aq[2 * k + 1];
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          swap32(bs[2 * j], bs[2 * j + 1]);
+          swap32(bq[2 * j], bq[2 * j + 1]);
+          cs[j] = bs[2 * j] + bs[2 * j + 1];
+          cq2[j] = bq[2 * j] + bq[2 * j + 1];
+        }
+        // the four waves of a wave group meet in the A ring slot that the last K-tile just left (nothing lands there
+        // before the next tile's second LOAD segment): [row 0..255][wave column 0..3] (sum, sum of squares)
+        char* sb = smem + (ca == 0 ? NA - 1 : ca - 1) * PART;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int ib = 4 * j + 2 * ((lane >> 5) & 1) + ((lane >> 4) & 1);
+          const int R = 16 * ib + (hi8 ? 8 : 0) + (lane & 7);
+          *(float2*)(sb + ((grp * 128 + R) * 4 + wc) * 8) = make_float2(cs[j], cq2[j]);
+        }
+        wait_lds();
+        seg_barrier();
+        if (tid < 256) {
+          const float4 u = *(const float4*)(sb + tid * 32), w = *(const float4*)(sb + tid * 32 + 16);
+          const int R = tid & 127, ib = R >> 4;
+          const int m = m0 + (tid >> 7) * 128 + i0 * 16 + R;
+          if (ib < NBLK && m < p.M && (!SLICE || (i0 + ib >= is0 && i0 + ib < is1)))
+            *(float2*)(p.stats_out + ((int64_t)m * VITM_STATS_PARTS + nt_) * 2) =
+                make_float2((u.x + u.z) + (w.x + w.z), (u.y + u.w) + (w.y + w.w));
+        }
+      }
     }
     STAMP(2);
   }
 }
 
-template <int EPI, int NBLK, bool SLICE>
+template <int EPI, int NBLK, bool SLICE, bool STATS = false>
 int launch_one(const GemmArgs& b, int grid, hipStream_t st) {
-  auto kfn = gemm_pp_kernel<EPI, NBLK, SLICE>;
+  auto kfn = gemm_pp_kernel<EPI, NBLK, SLICE, STATS>;
   VITM_LDS_OPTIN(kfn, SMEM, "vitm_gemm");
   hipLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3(NT), SMEM, st, b);
   VITM_CHECK_LAUNCH("vitm_gemm (256x256 tile)");
@@ -560,6 +640,16 @@ int launch(const GemmArgs& a, hipStream_t st) {
     if (S < 2) b.share = 0;
   }
   b.S = S;
+  if (EPI == VITM_EPI_RESIDUAL && b.stats_out != nullptr) {
+    constexpr int E = VITM_EPI_RESIDUAL;   // the only epilogue whose output feeds a LayerNorm
+    int rc = launch_one<E, 8, false, true>(b, grid, st);
+    if (rc != VITM_OK || !b.share) return rc;
+    switch (S) {
+      case 2: return launch_one<E, 4, true, true>(b, grid, st);
+      case 3: return launch_one<E, 3, true, true>(b, grid, st);
+      default: return launch_one<E, 2, true, true>(b, grid, st);
+    }
+  }
   int rc = launch_one<EPI, 8, false>(b, grid, st);
   if (rc != VITM_OK || !b.share) return rc;
   switch (S) {

@@ -15,6 +15,7 @@ LIB_PATH = os.environ.get(
     "VITM_GFX950_LIB", os.path.join(os.path.dirname(_HERE), "lib", "libvitm_gfx950.so"))
 
 BF16, F32 = 0, 1
+STATS_PARTS = 4   # VITM_STATS_PARTS
 EPI_BIAS, EPI_BIAS_GELU, EPI_LN, EPI_LN_GELU, EPI_RESIDUAL, EPI_DGELU = 0, 1, 2, 3, 4, 5
 
 
@@ -36,6 +37,9 @@ SIGNATURES = {
     "vitm_ln_stats": (c_int, [c_void_p, c_int, c_int64, c_int, c_int, c_float, c_void_p, c_void_p]),
     "vitm_gemm": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int,
                           c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+    "vitm_gemm_stats": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_int,
+                                c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int, c_int, c_float,
+                                c_void_p]),
     "vitm_patch_embed": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int64, c_int,
                                  c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
     "vitm_gemm_f32": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_int,

@@ -134,10 +134,23 @@ def ln_stats(x: torch.Tensor, M: int, D: int, eps: float, stats: Optional[torch.
     return stats
 
 
+def uses_big_tile(M: int, pk: "PackedLinear") -> bool:
+    """True when vitm_gemm runs (M, pk) on the persistent 256x256-tile kernel (bf16 only)."""
+    return pk.dtype == torch.bfloat16 and bool(_lib.load().vitm_gemm_uses_big_tile(M, pk.npad, pk.kpad))
+
+
+def new_carried_stats(M: int, device) -> torch.Tensor:
+    """Zeroed [M, VITM_STATS_PARTS, 2] buffer for the LayerNorm moments that vitm_gemm_stats carries between GEMMs."""
+    return torch.zeros((M, _lib.STATS_PARTS, 2), dtype=torch.float32, device=device)
+
+
 def gemm(A: torch.Tensor, pk: PackedLinear, out: torch.Tensor, epilogue: int, M: int,
-         stats: Optional[torch.Tensor] = None, resid: Optional[torch.Tensor] = None, row_group: int = 0) -> torch.Tensor:
+         stats: Optional[torch.Tensor] = None, resid: Optional[torch.Tensor] = None, row_group: int = 0,
+         stats_out: Optional[torch.Tensor] = None, stats_partial: bool = False, ln_eps: float = 0.0) -> torch.Tensor:
     """out[:, :npad] = epilogue(A[:, :kpad] . wp^T); A, out (and resid) are 2-D row-major views.
-    fp32 A runs the fp32 kernel (fp32 packed weight, fp32 out and resid)."""
+    fp32 A runs the fp32 kernel (fp32 packed weight, fp32 out and resid).
+    ``stats_out`` (RESIDUAL epilogue) / ``stats_partial`` (LN epilogues, with ``ln_eps``) carry the LayerNorm row
+    moments between GEMMs (vitm_gemm_stats; big-tile shapes only, see ``uses_big_tile``)."""
     assert A.stride(1) == 1 and out.stride(1) == 1
     assert A.shape[1] >= pk.kpad, "A operand narrower than the packed K"
     assert A.dtype == pk.dtype, f"A is {A.dtype} but the weight was packed as {pk.dtype}"
@@ -149,6 +162,13 @@ def gemm(A: torch.Tensor, pk: PackedLinear, out: torch.Tensor, epilogue: int, M:
             "vitm_gemm_f32")
         return out
     assert A.dtype == torch.bfloat16
+    if stats_out is not None or stats_partial:
+        assert row_group == 0 and out.dtype == torch.bfloat16
+        _lib.check(_lib.load().vitm_gemm_stats(
+            _p(A), A.stride(0), _p(pk.wp), pk.kpad, _p(out), out.stride(0), M, pk.npad, pk.kpad, epilogue,
+            _p(stats), _p(pk.s), _p(pk.c), _p(pk.g), _p(resid), 0 if resid is None else resid.stride(0),
+            _p(stats_out), 1 if stats_partial else 0, pk.K, float(ln_eps), _stream()), "vitm_gemm_stats")
+        return out
     _lib.check(_lib.load().vitm_gemm(
         _p(A), A.stride(0), _p(pk.wp), pk.kpad, _p(out), out.stride(0), _dt(out), M, pk.npad, pk.kpad, epilogue,
         _p(stats), _p(pk.s), _p(pk.c), _p(pk.g), _p(resid), 0 if resid is None else resid.stride(0), row_group,

@@ -33,6 +33,9 @@ from ..utils.helper import to_2tuple
 from .patch_embeddings import PatchEmbed, layernorm_params
 
 _SUPPORTED_HEAD_DIMS = (32, 64, 96, 128)
+# bf16, big-tile shapes: LayerNorm row moments ride from the proj / fc2 epilogue to the qkv / fc1 epilogue
+# (vitm_gemm_stats); False recomputes them with vitm_ln_stats in front of every LayerNorm-folded GEMM.
+CARRY_LN_STATS = True
 
 
 def _check_gelu(act: nn.Module, what: str) -> None:
@@ -259,25 +262,42 @@ class Block(nn.Module):
             _ops.layernorm(x2d, ws["xn"], M, D, _ops.f32vec(ln[0]), _ops.f32vec(ln[1]), ln[2])
             return ws["xn"]
 
+        # bf16 at large batch: the proj / fc2 epilogues also leave the row moments of the stream they write, so the
+        # LayerNorm in front of the next GEMM needs no pass of its own over x (ws["carried"]; ws["carried_valid"]
+        # says whether it describes the current x2d -- the first block of a forward starts from vitm_ln_stats)
+        proj_pk = attn._proj_pack(dt, self.ls1.gamma)
+        fc2_pk = mlp._fc2_pack(dt, self.ls2.gamma)
+        carry = (CARRY_LN_STATS and not f32 and ln1 is not None and ln2 is not None and D <= 256 * _ops._lib.STATS_PARTS
+                 and all(_ops.uses_big_tile(M, pk) for pk in (proj_pk, fc2_pk, attn._qkv_pack(dt, ln1), mlp._fc1_pack(dt, ln2))))
+        if carry and "carried" not in ws:
+            ws["carried"] = _ops.new_carried_stats(M, x2d.device)
+            ws["carried_valid"] = False
         # attention branch
         if ln1 is None:
             _ops.gemm(x2d, attn._qkv_pack(dt), ws["qkv"], _ops.EPI_BIAS, M)
         elif f32:
             _ops.gemm(normed(ln1), attn._qkv_pack(dt), ws["qkv"], _ops.EPI_BIAS, M)
+        elif carry and ws["carried_valid"]:
+            _ops.gemm(x2d, attn._qkv_pack(dt, ln1), ws["qkv"], _ops.EPI_LN, M, stats=ws["carried"], stats_partial=True,
+                      ln_eps=ln1[2])
         else:
             _ops.ln_stats(x2d, M, D, ln1[2], ws["stats"])
             _ops.gemm(x2d, attn._qkv_pack(dt, ln1), ws["qkv"], _ops.EPI_LN, M, stats=ws["stats"])
         attn._core(ws["qkv"], ws["o"], B, N)
-        _ops.gemm(ws["o"], attn._proj_pack(dt, self.ls1.gamma), x2d, _ops.EPI_RESIDUAL, M, resid=x2d)
+        _ops.gemm(ws["o"], proj_pk, x2d, _ops.EPI_RESIDUAL, M, resid=x2d, stats_out=ws["carried"] if carry else None)
         # MLP branch
         if ln2 is None:
             _ops.gemm(x2d, mlp._fc1_pack(dt), ws["h"], _ops.EPI_BIAS_GELU, M)
         elif f32:
             _ops.gemm(normed(ln2), mlp._fc1_pack(dt), ws["h"], _ops.EPI_BIAS_GELU, M)
+        elif carry:
+            _ops.gemm(x2d, mlp._fc1_pack(dt, ln2), ws["h"], _ops.EPI_LN_GELU, M, stats=ws["carried"], stats_partial=True,
+                      ln_eps=ln2[2])
         else:
             _ops.ln_stats(x2d, M, D, ln2[2], ws["stats"])
             _ops.gemm(x2d, mlp._fc1_pack(dt, ln2), ws["h"], _ops.EPI_LN_GELU, M, stats=ws["stats"])
-        _ops.gemm(ws["h"], mlp._fc2_pack(dt, self.ls2.gamma), x2d, _ops.EPI_RESIDUAL, M, resid=x2d)
+        _ops.gemm(ws["h"], fc2_pk, x2d, _ops.EPI_RESIDUAL, M, resid=x2d, stats_out=ws["carried"] if carry else None)
+        ws["carried_valid"] = carry
 
     def _workspace(self, M: int, device, dtype) -> dict:
         D = self.dim
