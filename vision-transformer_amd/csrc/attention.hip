@@ -195,6 +195,373 @@ int launch_attn(const void* qkv, int64_t ldq, void* out, int64_t ldo, int B, int
   return VITM_OK;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Short sequences (N <= 224 keys, head_dim 64: every 224-pixel ViT): persistent, exact two-pass softmax.
+//
+// One 8-wave workgroup per CU walks the (image, head) pairs.  Waves 0-6 each own a 32-query block; wave 7 only
+// moves data.  All K and V rows of a pair fit LDS (2 x 28 KiB), so the whole score strip S^T[keys, 32 queries] of a
+// wave (NT tiles x 16 registers) stays in registers: the row maximum is known before the first exponential, and the
+// online-softmax machinery (a running maximum, a cross-half exchange and a rescale of O per tile) disappears.  A
+// computing wave runs three long phases per pair:
+//   1. NT x 4 MFMAs   S^T = K . Q^T          (K fragments: ds_read_b128, one tile ahead)
+//   2. VALU only      max, exp2, bf16        (one exchange between the two 32-lane halves for the max)
+//   3. NT x 6 MFMAs   O^T += V^T . P^T       (V^T fragments: ds_read_b64_tr_b16, one k-step ahead; the row sums of P
+//                                            come from the same product against a fragment of ones, i.e. they are
+//                                            the sums of the bf16 values that the numerator uses, and cost no VALU)
+// and the two waves that share a SIMD are in different phases most of the time, so the matrix pipe and the VALU
+// overlap across waves without any interleaving inside a wave.
+// Every byte moves in whole 128-byte lines, 8 lines per wave instruction.  K and V rows of the workgroup's NEXT pair
+// are brought by wave 7 with LDS-DMA (1-KiB pieces of 8 rows x 128 B, no registers) into the other half of a
+// two-entry LDS ring while the current pair is computed: the address unit takes tens of cycles per piece, which a
+// computing wave cannot afford between its MFMAs.  Each computing wave has a 4-KiB LDS region of its own that holds
+// its Q rows (LDS-DMA, issued by the wave itself) until they are in registers, then turns the previous pair's
+// output tile into rows for whole-line stores, then receives the next pair's Q rows.  One barrier per pair.
+// Rows are unpadded (the DMA writes lane-linear); the 16-byte chunk index is XOR-ed, on the DMA's source address and
+// on the reads, with (row >> 1) & 7 for K, Q and the output tile (ds_read_b128 of 16 consecutive rows: 16 distinct
+// bank windows) and with 4 * ((row >> 1) & 1) for V (the 4 rows x 64 B of a transposing read cover all 64 banks).
+namespace short_seq {
+
+#ifdef ATTN_STAMP   // diagnostic build: lane 0 of every wave records s_memtime at phase boundaries into `lse`
+#define ASTAMP(kk)                                                                                      \
+  do {                                                                                                  \
+    unsigned long long t__;                                                                             \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__)::"memory");                          \
+    if (lane == 0 && k < 12) ((unsigned long long*)lse)[(((size_t)blockIdx.x * 12 + k) * 8 + wave) * 8 + (kk)] = t__; \
+  } while (0)
+#else
+#define ASTAMP(kk) do {} while (0)
+#endif
+
+constexpr int HD = 64, RS = 128, CWAVES = 7, NTH = (CWAVES + 1) * 64;
+constexpr int MAX_TILES = 7;                    // 224 keys
+constexpr int PARTB = MAX_TILES * 32 * RS;      // K (or V) rows of one pair: 28 KiB
+constexpr int BUFB = 2 * PARTB;                 // one ring entry
+constexpr int QBASE = 2 * BUFB;                 // per-wave Q / output regions follow the ring
+constexpr int QREG = 32 * RS;                   // 4 KiB
+constexpr int SMEM = QBASE + CWAVES * QREG;     // 140 KiB
+
+// LDS-DMA of 16 bytes per lane (1 KiB per wave) to LDS byte address `lds_addr` (wave-uniform) + 16 * lane, written as
+// inline asm so that the compiler does not know a load is in flight: with the builtin it drains every outstanding
+// piece (s_waitcnt vmcnt(0)) in front of the next transposing LDS read or LDS store, which would put the whole
+// memory latency of the prefetch into the middle of the compute phases.  Completion is this kernel's own business:
+// one "s_waitcnt vmcnt(0)" before the barrier that ends a pair.
+__device__ __forceinline__ void glds16(const void* g, unsigned lds_addr) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(g), "s"(lds_addr)
+               : "memory");
+}
+// a value and that of lane ^ 32, without the LDS crossbar (v_permlane32_swap of two copies)
+__device__ __forceinline__ void half_pair(float x, float& own, float& other) {
+  own = x;
+  other = x;
+  asm volatile("v_nop\n\tv_nop\n\tv_permlane32_swap_b32 %0, %1" : "+v"(own), "+v"(other));
+}
+__device__ __forceinline__ void swap32u(unsigned& a, unsigned& b) {
+  asm volatile("v_nop\n\tv_nop\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ void wait_lds() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void pair_done() {   // this wave's DMA landed, then everyone is done with the pair
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+}
+
+// WITH_LSE: also write the log-sum-exp of every query row (training); it is formed from the fp32 probabilities
+// (a VALU sum on top), while the output is normalised by the sum of the bf16 ones either way.
+template <int NT, bool WITH_LSE>   // key tiles of 32: 32 (NT - 1) < N <= 32 NT
+__global__ __launch_bounds__(NTH, 2) void attn_short_kernel(const bf16_t* __restrict__ qkv, int64_t ldq,
+                                                            bf16_t* __restrict__ out, int64_t ldo, int N, int H,
+                                                            float sl2e, int nitems, float* __restrict__ lse) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int D = H * HD;
+  const int my_items = blockIdx.x < nitems ? (nitems - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
+  if (my_items == 0) return;
+  const unsigned lds0 = (unsigned)(unsigned long)LPTR(smem);   // LDS byte address of the dynamic region
+  constexpr int NP = NT * 4;                                   // 8-row pieces per operand
+  auto pair_base = [&](int k) -> const bf16_t* {
+    const int item = blockIdx.x + k * gridDim.x;
+    const int b = item / H, h = item - b * H;
+    return qkv + (int64_t)b * N * ldq + h * HD;
+  };
+
+  if (wave == CWAVES) {
+    // ---- the mover: K rows then V rows of pair k + 1 into ring entry (k + 1) & 1 while pair k is computed.  Rows
+    // past N repeat row N - 1 (finite values: their scores are masked and their probabilities are exactly 0).
+    const int lr = lane >> 3;
+    const int kcol0 = ((lane & 7) ^ ((lane >> 4) & 3)) * 8;        // K chunk swizzle: (row >> 1) & 7, row = 8 pl + lr
+    const int kcol1 = ((lane & 7) ^ (((lane >> 4) & 3) | 4)) * 8;  //   odd pieces
+    const int vcol = ((lane & 7) ^ (4 * ((lane >> 4) & 1))) * 8;   // V chunk swizzle: 4 * ((row >> 1) & 1)
+    auto move_pair = [&](int k) {
+      const bf16_t* base = pair_base(k);
+      const unsigned dst = lds0 + (k & 1) * BUFB;
+#pragma unroll 4
+      for (int pl = 0; pl < NP; ++pl) {
+        int row = pl * 8 + lr;
+        row = row < N ? row : N - 1;
+        glds16(base + (int64_t)row * ldq + D + ((pl & 1) ? kcol1 : kcol0), dst + pl * 1024);
+      }
+#pragma unroll 4
+      for (int pl = 0; pl < NP; ++pl) {
+        int row = pl * 8 + lr;
+        row = row < N ? row : N - 1;
+        glds16(base + (int64_t)row * ldq + 2 * D + vcol, dst + PARTB + pl * 1024);
+      }
+    };
+    move_pair(0);
+    pair_done();
+    for (int k = 0; k < my_items; ++k) {
+      if (k + 1 < my_items) move_pair(k + 1);
+      pair_done();
+    }
+    return;
+  }
+
+  const int r = lane & 31, hh = lane >> 5;
+  const int q0 = wave * 32;
+  const bool active = q0 < N;   // wave-uniform
+  if (!active) {                // no queries for this wave: keep the barrier count
+    pair_done();
+    for (int k = 0; k < my_items; ++k) pair_done();
+    return;
+  }
+
+  // lane-constant offsets
+  const int fk = (r >> 1) & 7;
+  int koff[4];                  // fragment reads of K / Q rows and the output tile's writes: row r, chunk 2 s + hh
+#pragma unroll
+  for (int s = 0; s < 4; ++s) koff[s] = r * RS + (((2 * s + hh) ^ fk) * 16);
+  const int g16 = lane >> 4, li = lane & 15;
+  int voff[2];                  // transposing reads of V: 16-lane group = 4 keys x 16 dims
+#pragma unroll
+  for (int d = 0; d < 2; ++d)
+    voff[d] = (4 * hh + (li >> 2)) * RS + 64 * (d ^ ((li >> 3) & 1)) + 32 * (g16 & 1) + 8 * (li & 3);
+  int ooff[4];                  // output tile as rows: lane -> row 8 i + (lane >> 3), 16-byte chunk lane & 7
+  int64_t qsrc[4];              // Q pieces: element offset of this lane's 16 bytes of row q0 + 8 j + (lane >> 3)
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = 8 * i + (lane >> 3);
+    const int sw = (row >> 1) & 7;
+    ooff[i] = row * RS + (((lane & 7) ^ sw) * 16);
+    const int grow = q0 + row < N ? q0 + row : N - 1;
+    qsrc[i] = (int64_t)grow * ldq + ((lane & 7) ^ sw) * 8;
+  }
+  char* const qreg = smem + QBASE + wave * QREG;
+  const unsigned qreg_lds = lds0 + QBASE + wave * QREG;
+  auto issue_q = [&](const bf16_t* base) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) glds16(base + qsrc[j], qreg_lds + j * 1024);
+  };
+  // fragment of ones for the row sums: A-operand rows 0 and 4 (accumulator register 0 of the lower / upper half)
+  const unsigned one2 = ((lane & 31) == 0 || (lane & 31) == 4) ? 0x3f803f80u : 0u;
+  const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, make_uint4(one2, one2, one2, one2));
+
+  uint4 ost0, ost1, ost2, ost3;   // packed output of the previous pair: ostJ = dims 16 J + 8 hh .. + 7 of query r
+  ost0 = ost1 = ost2 = ost3 = make_uint4(0, 0, 0, 0);
+  // previous pair's tile -> rows (through this wave's region) -> global memory in whole lines; `dst` = the
+  // tile's first row, out + (b N + q0) ldo + h HD
+#define VITM_FLUSH_OUTPUT(dst)                                                                        \
+  do {                                                                                                \
+    *(uint4*)(qreg + koff[0]) = ost0;   /* dims 16 j + 8 hh .. + 7 = chunk 2 j + hh of row r */       \
+    *(uint4*)(qreg + koff[1]) = ost1;                                                                 \
+    *(uint4*)(qreg + koff[2]) = ost2;                                                                 \
+    *(uint4*)(qreg + koff[3]) = ost3;                                                                 \
+    wait_lds();                                                                                       \
+    const uint4 w0 = *(const uint4*)(qreg + ooff[0]), w1 = *(const uint4*)(qreg + ooff[1]);           \
+    const uint4 w2 = *(const uint4*)(qreg + ooff[2]), w3 = *(const uint4*)(qreg + ooff[3]);           \
+    wait_lds();                                                                                       \
+    bf16_t* op_ = (dst) + (int64_t)(lane >> 3) * ldo + (lane & 7) * 8;                                \
+    const int qr_ = q0 + (lane >> 3);                                                                 \
+    if (qr_ < N) *(uint4*)op_ = w0;                                                                   \
+    if (qr_ + 8 < N) *(uint4*)(op_ + 8 * ldo) = w1;                                                   \
+    if (qr_ + 16 < N) *(uint4*)(op_ + 16 * ldo) = w2;                                                 \
+    if (qr_ + 24 < N) *(uint4*)(op_ + 24 * ldo) = w3;                                                 \
+  } while (0)
+  auto out_base = [&](int k) -> bf16_t* {
+    const int item = blockIdx.x + k * gridDim.x;
+    const int b = item / H, h = item - b * H;
+    return out + ((int64_t)b * N + q0) * ldo + h * HD;
+  };
+
+  issue_q(pair_base(0));
+  pair_done();
+
+  for (int k = 0; k < my_items; ++k) {
+    const bool more = k + 1 < my_items;
+    const char* Kb = smem + (k & 1) * BUFB;
+    const char* Vb = Kb + PARTB;
+    ASTAMP(0);
+    // ---- Q fragments out of the region
+    bf16x8_t qf[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) qf[s] = *(const bf16x8_t*)(qreg + koff[s]);
+    bf16x8_t kf[2][4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) kf[0][s] = *(const bf16x8_t*)(Kb + koff[s]);
+    ASTAMP(1);
+    // ---- phase 1: S^T strip; K fragments one tile ahead
+    f32x16_t sacc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      if (t + 1 < NT) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) kf[(t + 1) & 1][s] = *(const bf16x8_t*)(Kb + (t + 1) * 32 * RS + koff[s]);
+      }
+#pragma unroll
+      for (int e = 0; e < 16; ++e) sacc[t][e] = 0.f;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) sacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[t & 1][s], qf[s], sacc[t], 0, 0, 0);
+    }
+    if (NT * 32 > N) {   // ragged last tile: keys past N contribute nothing
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int key = (NT - 1) * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+        if (key >= N) sacc[NT - 1][e] = -1e30f;
+      }
+    }
+    ASTAMP(2);
+    // ---- the region is free (Q is in registers): previous output through it, then the next pair's Q into it
+    if (k > 0) VITM_FLUSH_OUTPUT(out_base(k - 1));
+    if (more) issue_q(pair_base(k + 1));
+    // ---- phase 2: exact softmax of the strip
+    float m = sacc[0][0];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) m = fmaxf(m, sacc[t][e]);
+    float m_own, m_other;
+    half_pair(m, m_own, m_other);
+    m = fmaxf(m_own, m_other);
+    const float mb = m * sl2e;
+    bf16x8_t pb[NT][2];
+    float lsum = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        u16x8_t pk;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float pv = __builtin_amdgcn_exp2f(fmaf(sacc[t][8 * s2 + j], sl2e, -mb));
+          if (WITH_LSE) lsum += pv;
+          pk[j] = f2bf(pv);
+        }
+        pb[t][s2] = __builtin_bit_cast(bf16x8_t, pk);
+      }
+    }
+    ASTAMP(3);
+    // ---- phase 3: O^T += V^T . P^T ; element j of the A fragment is key 16 s2 + 8 (j >> 2) + 4 hh + (j & 3);
+    // V^T fragments one k-step (16 keys) ahead
+    f32x16_t o[2], osum;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) o[0][e] = o[1][e] = osum[e] = 0.f;
+    u16x4_t vf[2][4];   // [parity of the k-step][2 d + (lo, hi)]
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+      vf[0][2 * d] = tr_read(Vb + voff[d]);
+      vf[0][2 * d + 1] = tr_read(Vb + voff[d] + 8 * RS);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2 * NT; ++ks) {
+      if (ks + 1 < 2 * NT) {
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+          vf[(ks + 1) & 1][2 * d] = tr_read(Vb + (ks + 1) * 16 * RS + voff[d]);
+          vf[(ks + 1) & 1][2 * d + 1] = tr_read(Vb + (ks + 1) * 16 * RS + voff[d] + 8 * RS);
+        }
+      }
+      osum = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pb[ks >> 1][ks & 1], osum, 0, 0, 0);
+#pragma unroll
+      for (int d = 0; d < 2; ++d) {
+        const u16x4_t lo = vf[ks & 1][2 * d], hi = vf[ks & 1][2 * d + 1];
+        u16x8_t tv;
+        tv[0] = lo[0]; tv[1] = lo[1]; tv[2] = lo[2]; tv[3] = lo[3];
+        tv[4] = hi[0]; tv[5] = hi[1]; tv[6] = hi[2]; tv[7] = hi[3];
+        o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, tv), pb[ks >> 1][ks & 1], o[d], 0, 0, 0);
+      }
+    }
+    ASTAMP(4);
+    // ---- normalise, pack; pairs of 4-dim groups of the two halves are exchanged so a lane holds 8 consecutive
+    // dims (16 bytes): lower half dims 32 d + 16 p .. + 7, upper half dims 32 d + 16 p + 8 .. + 15
+    const float l = osum[0];    // sum over all keys of this lane's query (rows 0 / 4 of the ones product)
+    const float inv = __builtin_amdgcn_rcpf(l);
+#ifndef ATTN_STAMP
+    if (WITH_LSE) {
+      float ls_own, ls_other;
+      half_pair(lsum, ls_own, ls_other);
+      const int item = blockIdx.x + k * gridDim.x;
+      if (hh == 0 && q0 + r < N) lse[(int64_t)item * N + q0 + r] = mb + __log2f(ls_own + ls_other);   // item = b H + h
+    }
+#endif
+#define VITM_PACK_OUT(dst, d, pq)                                                          \
+  do {                                                                                    \
+    unsigned a0 = pack_bf2(o[d][8 * pq + 0] * inv, o[d][8 * pq + 1] * inv);               \
+    unsigned a1 = pack_bf2(o[d][8 * pq + 2] * inv, o[d][8 * pq + 3] * inv);               \
+    unsigned b0 = pack_bf2(o[d][8 * pq + 4] * inv, o[d][8 * pq + 5] * inv);               \
+    unsigned b1 = pack_bf2(o[d][8 * pq + 6] * inv, o[d][8 * pq + 7] * inv);               \
+    swap32u(a0, b0);                                                                      \
+    swap32u(a1, b1);                                                                      \
+    dst = make_uint4(a0, a1, b0, b1);                                                     \
+  } while (0)
+    VITM_PACK_OUT(ost0, 0, 0);
+    VITM_PACK_OUT(ost1, 0, 1);
+    VITM_PACK_OUT(ost2, 1, 0);
+    VITM_PACK_OUT(ost3, 1, 1);
+    ASTAMP(5);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ASTAMP(6);
+    __builtin_amdgcn_s_barrier();
+    ASTAMP(7);
+  }
+  VITM_FLUSH_OUTPUT(out_base(my_items - 1));
+#undef VITM_FLUSH_OUTPUT
+#undef VITM_PACK_OUT
+}
+
+template <int NT>
+int launch_nt(const void* qkv, int64_t ldq, void* out, int64_t ldo, int B, int N, int H, float scale, float* lse,
+              hipStream_t st) {
+  const int nitems = B * H;
+  const int ncu = vitm_cu_count();
+  const int grid = nitems < ncu ? nitems : ncu;
+  const float sl2e = scale * 1.4426950408889634f;
+  if (lse != nullptr) {
+    auto kfn = attn_short_kernel<NT, true>;
+    VITM_LDS_OPTIN(kfn, SMEM, "vitm_attention_lse");
+    hipLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3(NTH), SMEM, st, (const bf16_t*)qkv, ldq, (bf16_t*)out, ldo, N, H,
+                       sl2e, nitems, lse);
+  } else {
+#ifdef ATTN_STAMP
+    auto kfn = attn_short_kernel<NT, true>;
+#else
+    auto kfn = attn_short_kernel<NT, false>;
+#endif
+    VITM_LDS_OPTIN(kfn, SMEM, "vitm_attention");
+    hipLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3(NTH), SMEM, st, (const bf16_t*)qkv, ldq, (bf16_t*)out, ldo, N, H,
+                       sl2e, nitems, lse);
+  }
+  VITM_CHECK_LAUNCH("vitm_attention (short sequences)");
+  return VITM_OK;
+}
+
+int launch(const void* qkv, int64_t ldq, void* out, int64_t ldo, int B, int N, int H, float scale, float* lse,
+           hipStream_t st) {
+  switch ((N + 31) / 32) {
+    case 1: return launch_nt<1>(qkv, ldq, out, ldo, B, N, H, scale, lse, st);
+    case 2: return launch_nt<2>(qkv, ldq, out, ldo, B, N, H, scale, lse, st);
+    case 3: return launch_nt<3>(qkv, ldq, out, ldo, B, N, H, scale, lse, st);
+    case 4: return launch_nt<4>(qkv, ldq, out, ldo, B, N, H, scale, lse, st);
+    case 5: return launch_nt<5>(qkv, ldq, out, ldo, B, N, H, scale, lse, st);
+    case 6: return launch_nt<6>(qkv, ldq, out, ldo, B, N, H, scale, lse, st);
+    default: return launch_nt<7>(qkv, ldq, out, ldo, B, N, H, scale, lse, st);
+  }
+}
+
+}  // namespace short_seq
+
 }  // namespace
 
 static int attention_impl(const void* qkv, int64_t ldqkv, void* out, int64_t ldo, int B, int N, int H,
@@ -208,6 +575,8 @@ static int attention_impl(const void* qkv, int64_t ldqkv, void* out, int64_t ldo
   VITM_REQUIRE(((uintptr_t)qkv & 15) == 0 && ((uintptr_t)out & 15) == 0, "vitm_attention: pointers must be 16-byte aligned");
   VITM_REQUIRE(scale > 0.f, "vitm_attention: scale must be positive");
   hipStream_t st = (hipStream_t)stream;
+  if (head_dim == 64 && N <= 32 * short_seq::MAX_TILES && (int64_t)B * H < (1ll << 31))
+    return short_seq::launch(qkv, ldqkv, out, ldo, B, N, H, scale, lse, st);
   switch (head_dim) {
     case 32: return launch_attn<32>(qkv, ldqkv, out, ldo, B, N, H, scale, lse, st);
     case 64: return launch_attn<64>(qkv, ldqkv, out, ldo, B, N, H, scale, lse, st);
