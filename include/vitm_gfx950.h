@@ -314,7 +314,8 @@ int vitm_gelu_bwd(const void* pre, int64_t ldp, const void* dh, int64_t ldh, voi
 /*
  * loss[0] = mean over the batch of softmax cross-entropy(logits[b,:], labels[b]); dlogits (optional) its gradient.
  * nn.CrossEntropyLoss() with class-index targets (train.py:187,220).  row_loss: B floats of scratch (the per-image
- * losses, added in index order).
+ * losses, added in index order).  Labels must lie in [0, C): a label outside it (ignore_index -100 included, which is
+ * not implemented) gives that row a NaN loss -- hence a NaN mean -- and a zero gradient row, never an out-of-bounds read.
  */
 int vitm_cross_entropy_f32(const float* logits, int64_t ld, const int64_t* labels, int B, int C, float* loss,
                            float* dlogits, int64_t lddl, float* row_loss, vitm_stream_t stream);

@@ -554,11 +554,16 @@ __global__ __launch_bounds__(256) void cross_entropy_rows_kernel(const float* __
   float s = 0.f;
   for (int c = lane; c < C; c += 64) s += __expf(row[c] - mx);
   s = wave_sum(s);
-  const int y = (int)labels[r];
-  if (lane == 0) row_loss[r] = mx + __logf(s) - row[y];
+  // a label outside [0, C) -- nn.CrossEntropyLoss's ignore_index (-100) included, which this kernel does not implement --
+  // must not become an out-of-bounds read: the row's loss is NaN (so the mean is) and its gradient row is zero
+  const int64_t y64 = labels[r];
+  const bool ok = y64 >= 0 && y64 < (int64_t)C;
+  const int y = ok ? (int)y64 : 0;
+  if (lane == 0) row_loss[r] = ok ? mx + __logf(s) - row[y] : __builtin_nanf("");
   if (dlogits) {
     const float is = 1.0f / s;
-    for (int c = lane; c < C; c += 64) dlogits[(int64_t)r * lddl + c] = (__expf(row[c] - mx) * is - (c == y ? 1.f : 0.f)) * inv_b;
+    for (int c = lane; c < C; c += 64)
+      dlogits[(int64_t)r * lddl + c] = ok ? (__expf(row[c] - mx) * is - (c == y ? 1.f : 0.f)) * inv_b : 0.f;
   }
 }
 __global__ __launch_bounds__(64) void cross_entropy_mean_kernel(const float* __restrict__ row_loss, int B, float* __restrict__ loss) {
