@@ -321,6 +321,19 @@ int vitm_cross_entropy_f32(const float* logits, int64_t ld, const int64_t* label
                            float* dlogits, int64_t lddl, float* row_loss, vitm_stream_t stream);
 
 /*
+ * vitm_cross_entropy_f32 for callers that cannot allocate device memory (code under HIP graph capture, tight serving
+ * or training loops, harnesses that forbid hipMalloc): no counterpart in the reference.  Same arithmetic and results
+ * as vitm_cross_entropy_f32, bit for bit; the per-row losses go to a device array inside the library (64 KiB per GPU,
+ * held until the process ends) instead of `row_loss`, so B is limited to vitm_cross_entropy_noalloc_max_rows()
+ * (16384) -- a larger B is refused with VITM_EINVAL.  The call allocates and frees nothing.  The first call on a
+ * device looks the array's address up (hipGetSymbolAddress): make that call outside a graph capture.  All calls on one
+ * GPU share the array: calls that overlap on one GPU (different streams) race; calls on one stream are ordered.
+ */
+int vitm_cross_entropy_f32_noalloc(const float* logits, int64_t ld, const int64_t* labels, int B, int C, float* loss,
+                                   float* dlogits, int64_t lddl, vitm_stream_t stream);
+int vitm_cross_entropy_noalloc_max_rows(void);
+
+/*
  * torch.nn.utils.clip_grad_norm_(parameters, max_norm) (train.py:222) on one flat gradient buffer of n floats:
  * norm_and_coef[0] = L2 norm, [1] = min(1, max_norm / (norm + 1e-6)), grads *= [1].  `scratch` holds
  * vitm_grad_clip_scratch_floats() floats.

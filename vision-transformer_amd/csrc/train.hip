@@ -749,6 +749,54 @@ extern "C" int vitm_cross_entropy_f32(const float* logits, int64_t ld, const int
   return VITM_OK;
 }
 
+// ---- the same loss for callers that cannot allocate: the per-row losses go to a file-scope device array instead of a
+// caller-supplied buffer.  Each GPU holds its own copy of the array; its address on a device is looked up once, with
+// that device current, and kept.
+constexpr int CE_NOALLOC_MAX_ROWS = 16384;
+static __device__ __align__(256) float scratch[CE_NOALLOC_MAX_ROWS];
+
+static int scratch_on_current_device(float** out) {
+  constexpr int MAXDEV = 64;
+  static std::atomic<float*> ptrs[MAXDEV];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAXDEV) {
+    vitm_set_error("vitm_cross_entropy_f32_noalloc: cannot identify the current device");
+    return VITM_ELAUNCH;
+  }
+  float* p = ptrs[dev].load(std::memory_order_acquire);
+  if (p == nullptr) {
+    void* sym = nullptr;
+    const hipError_t e = hipGetSymbolAddress(&sym, HIP_SYMBOL(scratch));
+    if (e != hipSuccess || sym == nullptr) {
+      vitm_set_error("vitm_cross_entropy_f32_noalloc: hipGetSymbolAddress failed: %s", hipGetErrorString(e));
+      (void)hipGetLastError();
+      return VITM_ELAUNCH;
+    }
+    p = (float*)sym;
+    ptrs[dev].store(p, std::memory_order_release);   // every thread that races here stores the same address
+  }
+  *out = p;
+  return VITM_OK;
+}
+
+extern "C" int vitm_cross_entropy_f32_noalloc(const float* logits, int64_t ld, const int64_t* labels, int B, int C,
+                                              float* loss, float* dlogits, int64_t lddl, vitm_stream_t stream) {
+  VITM_REQUIRE(logits && labels && loss, "vitm_cross_entropy_f32_noalloc: null pointer");
+  VITM_REQUIRE(B > 0 && C > 0 && ld >= C && (!dlogits || lddl >= C), "vitm_cross_entropy_f32_noalloc: bad shape");
+  VITM_REQUIRE(B <= CE_NOALLOC_MAX_ROWS, "vitm_cross_entropy_f32_noalloc: B=%d exceeds the built-in scratch of %d rows "
+               "(use vitm_cross_entropy_f32 with a caller-supplied row_loss buffer)", B, CE_NOALLOC_MAX_ROWS);
+  float* row_loss = nullptr;
+  const int rc = scratch_on_current_device(&row_loss);
+  if (rc != VITM_OK) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  // rows 0 .. B-1 of the array are rewritten in full by every call: nothing has to start at zero
+  hipLaunchKernelGGL(cross_entropy_rows_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, st, logits, ld, labels, B, C, row_loss, dlogits, lddl);
+  hipLaunchKernelGGL(cross_entropy_mean_kernel, dim3(1), dim3(64), 0, st, (const float*)row_loss, B, loss);
+  VITM_CHECK_LAUNCH("vitm_cross_entropy_f32_noalloc");
+  return VITM_OK;
+}
+extern "C" int vitm_cross_entropy_noalloc_max_rows(void) { return CE_NOALLOC_MAX_ROWS; }
+
 extern "C" int vitm_grad_clip_f32(float* grads, int64_t n, float max_norm, float* scratch, float* norm_and_coef,
                                   vitm_stream_t stream) {
   VITM_REQUIRE(grads && scratch && norm_and_coef, "vitm_grad_clip_f32: null pointer");

@@ -82,6 +82,8 @@ SIGNATURES = {
     "vitm_gelu_bwd": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
     "vitm_cross_entropy_f32": (c_int, [c_void_p, c_int64, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int64, c_void_p,
                                        c_void_p]),
+    "vitm_cross_entropy_f32_noalloc": (c_int, [c_void_p, c_int64, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int64, c_void_p]),
+    "vitm_cross_entropy_noalloc_max_rows": (c_int, []),
     "vitm_grad_clip_f32": (c_int, [c_void_p, c_int64, c_float, c_void_p, c_void_p, c_void_p]),
     "vitm_grad_clip_scratch_floats": (c_int, []),
     "vitm_adamw_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float, c_float,
