@@ -39,7 +39,7 @@ import weights as W  # noqa: E402
 
 PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA, MI355X
 PEAK_HBM_GBS = 8000.0
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r1_fc1_traffic.json")  # PMC-measured HBM bytes per fc1 launch
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r2_fc1_traffic.json")  # PMC-measured HBM bytes per fc1 launch
 
 
 def measured_traffic(config, batch):

@@ -1,9 +1,9 @@
 #!/bin/bash
-# Profile collection for one round (run on the GPU box from the repo root):  bash profiles/collect.sh r1
+# Profile collection for one round (run on the GPU box from the repo root):  bash profiles/collect.sh r2
 # Pass 1: kernel trace + stats of the bench command.  Passes 2-4: PMC counters, each in a run of its own with
 # kernel-trace only (TCC FETCH_SIZE and WRITE_SIZE do not fit one pass; SQ counters a third).
 set -e
-R=${1:-r1}
+R=${1:-r2}
 OUT=gpurun_out/prof_$R
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"

@@ -1,13 +1,14 @@
 """Condense the rocprofv3 output of profiles/collect.sh into the committed per-round summaries.
 
-    python profiles/summarize.py r1        # reads gpurun_out/prof_r1/, writes profiles/r1_*.{csv,json}
+    python profiles/summarize.py r2        # reads gpurun_out/prof_r2/, writes profiles/r2_*.{csv,json}
 
 * <round>_kernel_stats.csv   -- the --stats table of the kernel-trace pass (per kernel: calls, average, share);
 * <round>_pmc_counters.csv   -- per kernel and counter, the per-dispatch average of every --pmc pass, with derived
                                 rows: HBM bytes per launch (FETCH_SIZE and WRITE_SIZE are reported in KiB; on gfx950
                                 FETCH_SIZE counts 64-byte requests as 32, hence x2), GB/s over the traced average
                                 duration, and MFMA busy fraction = SQ_VALU_MFMA_BUSY_CYCLES / (SIMDs x kernel cycles);
-* <round>_fc1_traffic.json   -- HBM bytes per launch of the dominant kernel (the fc1 GEMM), read by bench.py.
+* <round>_fc1_traffic.json   -- HBM bytes per launch of the dominant kernel (the fc1 GEMM), read by bench.py;
+* <round>_forward_traffic.json -- HBM bytes of a whole forward (all kernels), read by bench.py.
 """
 from __future__ import annotations
 
@@ -85,10 +86,10 @@ def main(rnd: str) -> None:
                 w.writerow([k, "=MFMA_BUSY_FRACTION (busy cycles / (1024 SIMDs x kernel cycles))",
                             f"{c['SQ_VALU_MFMA_BUSY_CYCLES'][0] / (SIMDS * cycles):.4f}", ""])
     # ---- fc1 traffic for bench.py
-    fc1 = [k for k in per if k.startswith("gemm_pp_kernel<3, 8, false>") or k.startswith("gemm_pp_kernel<3>")]
+    fc1 = [k for k in per if k.startswith("gemm_pp_kernel<3, 8, false")]
     if fc1 and "FETCH_SIZE" in per[fc1[0]] and "WRITE_SIZE" in per[fc1[0]]:
         c = per[fc1[0]]
-        slice_k = [k for k in per if k.startswith("gemm_pp_kernel<3, 2, true>")]
+        slice_k = [k for k in per if k.startswith("gemm_pp_kernel<3, 2, true")]
         hbm = c["FETCH_SIZE"][0] * 2048 + c["WRITE_SIZE"][0] * 1024
         extra = 0.0
         if slice_k and "FETCH_SIZE" in per[slice_k[0]]:
@@ -99,6 +100,24 @@ def main(rnd: str) -> None:
                    "note": "FETCH_SIZE x2 (gfx950 counts 64-byte requests as 32 bytes); separate --pmc passes; main "
                            "launch plus the leftover-tile slice launch of one fc1 GEMM"},
                   open(os.path.join(out, f"{rnd}_fc1_traffic.json"), "w"), indent=1)
+    # ---- HBM bytes of a whole forward: sum over kernels of (bytes per dispatch) x (dispatches per forward); the
+    # dispatch counts come from the kernel-trace pass, one embed_finalize launch = one forward
+    if stats:
+        calls = {short(r["Name"]): int(r["Calls"]) for r in rows}
+        fwd = calls.get("embed_finalize_kernel<unsigned short>", 0)
+        if fwd:
+            total, parts = 0.0, {}
+            for k, c in per.items():
+                if "FETCH_SIZE" in c and "WRITE_SIZE" in c and k in calls and calls[k] >= fwd:
+                    b = (c["FETCH_SIZE"][0] * 2048 + c["WRITE_SIZE"][0] * 1024) * (calls[k] / fwd)
+                    total += b
+                    parts[k] = round(b)
+            json.dump({"config": "vit_b16", "batch_per_gpu": 256, "hbm_bytes_per_forward": round(total),
+                       "hbm_bytes_per_image": round(total / 256), "per_kernel_bytes_per_forward": parts,
+                       "note": "sum over kernels launched at least once per forward of (2 x FETCH_SIZE KiB + WRITE_SIZE KiB) "
+                               "per dispatch x dispatches per forward; FETCH_SIZE doubled per the gfx950 correction; "
+                               "FETCH_SIZE counts what an XCD's L2 misses, whether HBM or the Infinity Cache serves it"},
+                      open(os.path.join(out, f"{rnd}_forward_traffic.json"), "w"), indent=1)
     print("wrote", sorted(os.listdir(out)))
 
 

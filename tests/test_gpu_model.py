@@ -203,6 +203,38 @@ def test_batch_independence_and_determinism():
     assert torch.equal(full, halves)
 
 
+def test_full_size_forward_properties():
+    """The benchmarked workload itself -- ViT-B/16 224, bf16, batch 256 -- through size-independent properties:
+    two runs are bit-identical; the batch equals the concatenation of its halves bit for bit (batch 128 takes the same
+    kernels: 256x256 tiles, carried LayerNorm moments, the persistent attention kernel); eight shards of 32 take the
+    128x128 GEMM and vitm_ln_stats instead, so they agree to bf16 rounding rather than bitwise; and images 0-1 are
+    those of the batch-2 golden fixture, whose fp32 reference logits they must match like the batch-2 run does."""
+    g = np.load(os.path.join(GOLD, "vit_b16.npz"))
+    seed = int(g["seed"])
+    model, sd, cfg = build("vit_b16", seed)
+    x2 = torch.from_numpy(W.make_input(cfg, 2, seed + 1))
+    rest = torch.from_numpy(W.make_input(cfg, 254, seed + 2))
+    x = torch.cat([x2, rest]).cuda().to(torch.bfloat16)
+    with torch.no_grad():
+        full = model(x)
+        again = model(x)
+        halves = torch.cat([model(x[:128]), model(x[128:])])
+        shards = torch.cat([model(x[i:i + 32]) for i in range(0, 256, 32)])
+        small = model(x[:2])
+    assert torch.isfinite(full.float()).all()
+    assert torch.equal(full, again), "run-to-run"
+    assert torch.equal(full, halves), "batch 256 vs two halves of 128"
+    ref = torch.from_numpy(g["logits"])
+    yard = torch.from_numpy(g["logits_ref_bf16"])
+    # two bf16 evaluation orders of one network: no further apart than the reference's own bf16 forward is from fp32
+    d = (full.float() - shards.float()).abs().cpu()
+    y = (yard - ref).abs()
+    assert d.pow(2).mean().sqrt().item() <= y.pow(2).mean().sqrt().item() and d.max().item() <= 2 * y.max().item(), \
+        (d.max().item(), d.pow(2).mean().sqrt().item())
+    check_logits("vit_b16 rows 0-1 of batch 256", full[:2], ref, yard)
+    check_logits("vit_b16 batch 2", small, ref, yard)
+
+
 @pytest.mark.parametrize("name,batch", [("vit_tiny_cifar", 16), ("vit_s16", 4)])
 def test_graph_replay_is_bit_identical(name, batch):
     """The forward captured into a HIP graph replays the same kernels on the same buffers."""

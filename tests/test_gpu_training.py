@@ -185,6 +185,39 @@ def test_bf16_training_with_padding_tracks_float64(monkeypatch):
         assert c >= (0.99 if p.numel() >= 1000 else 0.95), f"{k}: {c:.4f}"
 
 
+def test_vit_l16_bf16_training_step_tracks_float64(monkeypatch):
+    """ViT-L/16 shapes (embed 1024, 16 heads of 64, hidden 4096, 197 tokens, 1000 classes) at depth 2, batch 4:
+    the bf16 mixed-precision step (autograd interface for the gradients, then Trainer.step) against float64 autograd of
+    the oracle on the same weights; bars of test_bf16_training_with_padding_tracks_float64."""
+    from oracle import vit_oracle as O
+    from vitm_amd import training
+    cfg = dict(W.CONFIGS["vit_l16"], depth=2)
+    model = _model(cfg, 31).cpu()
+    sd64 = {k: v.detach().double().requires_grad_(True) for k, v in model.state_dict().items()}
+    x = torch.from_numpy(W.make_input(cfg, 4, 32)).to(torch.bfloat16)
+    y = torch.tensor([5, 999, 0, 417])
+    monkeypatch.setattr(O, "_t", lambda sd, key, dtype: None if sd.get(key) is None else sd[key].to(dtype))
+    loss64 = torch.nn.functional.cross_entropy(O.vitc_forward(x.double(), sd64, W.oracle_cfg(cfg), dtype=torch.float64), y)
+    loss64.backward()
+    norm64 = torch.sqrt(sum((v.grad ** 2).sum() for v in sd64.values() if v.grad is not None)).item()
+    model = model.cuda()
+    loss = training.CrossEntropyLoss()(model(x.cuda()), y.cuda())
+    loss.backward()
+    assert abs(loss.item() - loss64.item()) <= 1e-2 * abs(loss64.item())
+    for k, p in model.named_parameters():
+        c = _cos(p.grad.cpu(), sd64[k].grad)
+        assert c >= (0.99 if p.numel() >= 1000 else 0.95), f"{k}: {c:.4f}"
+    # the whole step: forward, loss, backward into the flat buffer, clip to 1.0, AdamW
+    opt, sched = training.reference_optimizer_and_scheduler(model, 1000)
+    before = {k: p.detach().clone() for k, p in model.named_parameters()}
+    tr = training.Trainer(model, opt, sched, max_norm=1.0, compute_dtype=torch.bfloat16)
+    step_loss = tr.step(x.cuda(), y.cuda())
+    assert abs(step_loss.item() - loss64.item()) <= 1e-2 * abs(loss64.item())
+    assert abs(tr.last_grad_norm.item() - norm64) <= 3e-2 * norm64
+    moved = max((p.detach() - before[k]).abs().max().item() for k, p in model.named_parameters())
+    assert 0 < moved <= 2e-5      # first step: lr = 0.01 * 1e-3, AdamW update of unit size
+
+
 # ---- flat parameters / single-launch AdamW -------------------------------------------------------------------------
 def _batch(cfg, batch, seed):
     x = torch.from_numpy(W.make_input(cfg, batch, seed)).cuda()
@@ -379,3 +412,54 @@ def test_checkpoint_round_trip_of_a_trainer(tmp_path):
     assert la.item() == lb.item()
     for (k, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):
         assert torch.equal(pa, pb), k
+
+
+def test_flat_adamw_state_loads_into_torch_adamw_with_one_step_per_parameter():
+    """The optimizer state a flat-mode Trainer saves must load into torch.optim.AdamW (the reference's optimizer) with
+    a step counter per parameter: one shared counter would advance once per parameter per iteration there."""
+    import io
+    from vitm_amd import training
+    cfg = W.CONFIGS["tiny2"]
+    a = _model(cfg, 5)
+    opt = training.AdamW(a.parameters(), lr=1e-3, weight_decay=0.05, betas=(0.9, 0.98))
+    tr = training.Trainer(a, opt, None, max_norm=1.0)
+    for step in range(2):
+        tr.step(*_batch(cfg, 4, 300 + step))
+    buf = io.BytesIO()
+    torch.save(opt.state_dict(), buf)
+    buf.seek(0)
+    sd = torch.load(buf, weights_only=True)
+    steps = [st["step"] for st in sd["state"].values()]
+    assert all(float(t) == 2 for t in steps) and len({id(t) for t in steps}) == len(steps)
+    b = _model(cfg, 5)
+    topt = torch.optim.AdamW(b.parameters(), lr=1e-3, weight_decay=0.05, betas=(0.9, 0.98))
+    topt.load_state_dict(sd)
+    for p in b.parameters():
+        p.grad = torch.zeros_like(p)
+    topt.step()
+    assert all(float(st["step"]) == 3 for st in topt.state.values())
+    # and back: a checkpoint whose entries alias one step tensor is de-aliased on load
+    shared = torch.tensor(7.0)
+    for st in sd["state"].values():
+        st["step"] = shared
+    opt.load_state_dict(sd)
+    tr.step(*_batch(cfg, 4, 310))
+    assert all(float(st["step"]) == 8 for st in opt.state.values())
+
+
+def test_trainer_with_a_frozen_parameter():
+    """Fine-tuning with part of the model frozen: the frozen tensors get no gradient and do not move."""
+    from vitm_amd import training
+    cfg = W.CONFIGS["tiny2"]
+    m = _model(cfg, 6)
+    m.vit_model.pos_embed.requires_grad_(False)
+    m.vit_model.blocks[0].attn.qkv.weight.requires_grad_(False)
+    frozen = {k: p.detach().clone() for k, p in m.named_parameters() if not p.requires_grad}
+    opt = training.AdamW([p for p in m.parameters() if p.requires_grad], lr=1e-3)
+    tr = training.Trainer(m, opt, None, max_norm=1.0)
+    l0 = tr.step(*_batch(cfg, 4, 400))
+    l1 = tr.step(*_batch(cfg, 4, 400))
+    assert torch.isfinite(l0) and l1 < l0
+    for k, p in m.named_parameters():
+        if k in frozen:
+            assert torch.equal(p.detach(), frozen[k]) and p.grad is None

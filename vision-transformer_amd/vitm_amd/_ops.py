@@ -144,6 +144,23 @@ def new_carried_stats(M: int, device) -> torch.Tensor:
     return torch.zeros((M, _lib.STATS_PARTS, 2), dtype=torch.float32, device=device)
 
 
+_carried_cache = {}
+
+
+def carried_stats(M: int, width: int, device) -> torch.Tensor:
+    """The carried-moments buffer for rows M of a stream `width` columns wide, kept between forwards: the producing
+    epilogues rewrite the slots of their column tiles in full and never touch the others, which therefore stay zero, so
+    nothing has to be cleared per call.  One buffer per (device, M, column tiles): forwards that overlap on one device
+    (several streams) must not share it -- use new_carried_stats() for those."""
+    key = (torch.device(device).index, M, (width + 255) // 256)
+    buf = _carried_cache.get(key)
+    if buf is None:
+        if len(_carried_cache) >= 8:
+            _carried_cache.clear()
+        buf = _carried_cache[key] = new_carried_stats(M, device)
+    return buf
+
+
 def gemm(A: torch.Tensor, pk: PackedLinear, out: torch.Tensor, epilogue: int, M: int,
          stats: Optional[torch.Tensor] = None, resid: Optional[torch.Tensor] = None, row_group: int = 0,
          stats_out: Optional[torch.Tensor] = None, stats_partial: bool = False, ln_eps: float = 0.0) -> torch.Tensor:

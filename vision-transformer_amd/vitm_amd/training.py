@@ -69,6 +69,8 @@ def supported(model) -> Optional[str]:
         return "patch embedding must be this package's PatchEmbed(flatten=True)"
     if vt.pos_embed is None:
         return "a learnable position embedding is required"
+    if vt.embed_dim % 8 != 0:
+        return "embed_dim must be a multiple of 8 for the activation-keeping forward"
     for blk in vt.blocks:
         if type(blk) is ParallelBlock:
             continue
@@ -219,7 +221,9 @@ class _Grads(dict):
 
     def buf(self, p: torch.Tensor, *shape) -> torch.Tensor:
         """The (uninitialised) gradient tensor of p, viewed as ``shape`` (default: flat)."""
-        t = self.sink[p] if self.sink is not None else torch.empty(p.shape, dtype=F32, device=p.device)
+        t = self.sink.get(p) if self.sink is not None else None
+        if t is None:   # no sink, or a frozen parameter (requires_grad False) that the flat buffer does not hold
+            t = torch.empty(p.shape, dtype=F32, device=p.device)
         self[p] = t
         return t.view(*shape) if shape else t.view(-1)
 
@@ -512,6 +516,8 @@ class FlatGradients:
 
     def __init__(self, params):
         self.params = [p for p in params if p.requires_grad]
+        if not self.params:
+            raise ValueError("FlatGradients: no parameter requires a gradient")
         self.offsets, total = _flat_layout(self.params)
         dev = self.params[0].device
         self.flat = torch.zeros(total, dtype=F32, device=dev)
@@ -611,6 +617,8 @@ class FlatParameters:
 
     def __init__(self, params):
         self.params = [p for p in params if p.requires_grad]
+        if not self.params:
+            raise ValueError("FlatParameters: no parameter requires a gradient")
         if any(p.dtype != F32 or not p.is_cuda for p in self.params):
             raise TypeError("FlatParameters holds fp32 CUDA parameters")
         self.offsets, total = _flat_layout(self.params)
@@ -652,7 +660,8 @@ class AdamW(torch.optim.Optimizer):
 
     def _seed_flat_state(self) -> None:
         """Per-parameter state entries become views of the flat moment buffers (torch's state_dict layout is kept);
-        existing state (a loaded checkpoint) is copied in first.  All parameters share one step counter."""
+        existing state (a loaded checkpoint) is copied in first.  Every parameter keeps a step counter of its own (as
+        torch.optim.AdamW does: a state_dict saved here must load into it), all advanced together by ``_flat_step``."""
         params, _, m, v = self._flat
         step = None
         for p, off in zip(params.params, params.offsets):
@@ -663,12 +672,21 @@ class AdamW(torch.optim.Optimizer):
                 vv.copy_(st["exp_avg_sq"])
                 step = st["step"] if step is None else step
             st["exp_avg"], st["exp_avg_sq"] = mv, vv
-        step = torch.tensor(0.0) if step is None else torch.as_tensor(float(step))
+        step = 0.0 if step is None else float(step)
         for p in params.params:
-            self.state[p]["step"] = step
+            self.state[p]["step"] = torch.tensor(step)
 
     def load_state_dict(self, state_dict) -> None:
         super().load_state_dict(state_dict)
+        # a checkpoint whose parameters share ONE step tensor (written by an older flat-mode optimizer) must not stay
+        # aliased: every in-place "step += 1" would then count once per parameter
+        seen = set()
+        for st in self.state.values():
+            t = st.get("step")
+            if torch.is_tensor(t):
+                if id(t) in seen:
+                    st["step"] = t.clone()
+                seen.add(id(st["step"]))
         if self._flat is not None:
             self._seed_flat_state()
 
@@ -677,8 +695,9 @@ class AdamW(torch.optim.Optimizer):
         group = self.param_groups[0]
         if not params.intact() or any(p.grad is None or p.grad.data_ptr() != grads.views[p].data_ptr() for p in params.params):
             return False
+        for p in params.params:
+            self.state[p]["step"] += 1
         step = self.state[params.params[0]]["step"]
-        step += 1
         b1, b2 = group["betas"]
         with torch.cuda.device(params.flat.device):
             T.adamw(params.flat, grads.flat, m, v, group["lr"], b1, b2, group["eps"], group["weight_decay"], int(step.item()))
@@ -749,6 +768,25 @@ class Trainer:
         self.criterion = CrossEntropyLoss()
         self.last_grad_norm = None
         self.reducer = GradientReducer(self.grads, group, bucket_bytes)
+        if self.reducer.active:
+            self.sync_from_rank0()
+
+    def sync_from_rank0(self) -> None:
+        """Data-parallel replicas must start identical: rank 0's parameters (and floating-point buffers) replace every
+        other rank's, as DistributedDataParallel does at construction.  Optimizer state is NOT synchronised: create the
+        optimizer fresh on every rank, or load the same checkpoint on every rank."""
+        import torch.distributed as dist
+        src = dist.get_global_rank(self.group, 0) if self.group is not None else 0
+        with torch.no_grad():
+            if self.params is not None and self.params.intact():
+                dist.broadcast(self.params.flat, src=src, group=self.group)
+                frozen = [p for p in self.model.parameters() if not p.requires_grad]
+            else:
+                frozen = list(self.model.parameters())
+            for t in frozen + [b for b in self.model.buffers() if b.is_floating_point()]:
+                dist.broadcast(t.data, src=src, group=self.group)
+            for p in self.model.parameters():
+                torch.autograd.graph.increment_version(p)   # cached packed weights must be rebuilt
 
     def step(self, images: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
         """zero_grad, forward, loss, backward, all-reduce, clip, optimizer and scheduler step.  The backward kernels
