@@ -15,6 +15,7 @@
 //
 // LDS rows are padded by 16 bytes (row = head_dim*2 + 16 bytes) which makes the 16-byte K fragment
 // reads bank-conflict free.  The score matrix never leaves registers.
+#include <type_traits>
 #include "common.h"
 
 namespace {
@@ -521,6 +522,332 @@ __global__ __launch_bounds__(NTH, 2) void attn_short_kernel(const bf16_t* __rest
 #undef VITM_PACK_OUT
 }
 
+// ---- longer sequences (head_dim 64, any N): the same machinery with the keys in chunks of 224 ----------------------
+// An item is (image, head, group of 7 query blocks); its K and V rows stream through the two-entry ring in chunks of up
+// to 224 keys (the mover runs one chunk ahead, across items).  Within a chunk the softmax is the exact two-pass one of
+// the strip; across chunks a running maximum rescales O and the row sums once per chunk (2-3 times per item at 577
+// tokens, against 18 times per item for a tile-by-tile online softmax).  The query groups of one (image, head) are
+// dealt to workgroups of one XCD (blockIdx & 7), so their K / V chunks are fetched from memory once and then from L2.
+template <int NTL, bool WITH_LSE>   // NTL: key tiles of the LAST chunk, 32 (NTL - 1) < N - 224 (nchunks - 1) <= 32 NTL
+__global__ __launch_bounds__(NTH, 2) void attn_chunked_kernel(const bf16_t* __restrict__ qkv, int64_t ldq,
+                                                              bf16_t* __restrict__ out, int64_t ldo, int N, int H,
+                                                              float sl2e, int nunits, float* __restrict__ lse) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int CK = 32 * MAX_TILES;   // keys per chunk, queries per group
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int D = H * HD;
+  const int nchunks = (N + CK - 1) / CK, QG = nchunks;
+  // items of this workgroup: XCD group x = blockIdx & 7 owns the units (image, head) u = x, x + 8, ...; its local items
+  // (unit, query group), unit-major, are dealt round-robin to the group's workgroups
+  const int xg = blockIdx.x & 7, lb = blockIdx.x >> 3, nloc = (gridDim.x + 7 - xg) >> 3;
+  const int units_x = nunits > xg ? (nunits - xg + 7) >> 3 : 0;
+  const int loc_items = units_x * QG;
+  const int my_items = lb < loc_items ? (loc_items - lb + nloc - 1) / nloc : 0;
+  if (my_items == 0) return;
+  const unsigned lds0 = (unsigned)(unsigned long)LPTR(smem);
+  auto item_of = [&](int k, int& unit, int& qg) {
+    const int li = lb + k * nloc;
+    const int ul = li / QG;
+    qg = li - ul * QG;
+    unit = ul * 8 + xg;
+  };
+  auto unit_base = [&](int unit) -> const bf16_t* {
+    const int b = unit / H, h = unit - b * H;
+    return qkv + (int64_t)b * N * ldq + h * HD;
+  };
+
+  if (wave == CWAVES) {
+    // ---- the mover: chunk (step % nchunks) of item (step / nchunks) into ring entry step & 1, one step ahead
+    const int lr = lane >> 3;
+    const int kcol0 = ((lane & 7) ^ ((lane >> 4) & 3)) * 8;
+    const int kcol1 = ((lane & 7) ^ (((lane >> 4) & 3) | 4)) * 8;
+    const int vcol = ((lane & 7) ^ (4 * ((lane >> 4) & 1))) * 8;
+    const int nsteps = my_items * nchunks;
+    auto move_step = [&](int step) {
+      const int k = step / nchunks, c = step - k * nchunks;
+      int unit, qg;
+      item_of(k, unit, qg);
+      const bf16_t* base = unit_base(unit);
+      const int k0 = c * CK;
+      const int rows = N - k0 < CK ? N - k0 : CK;
+      const int np = ((rows + 31) >> 5) * 4;
+      const unsigned dst = lds0 + (step & 1) * BUFB;
+      for (int pl = 0; pl < np; ++pl) {
+        int row = k0 + pl * 8 + lr;
+        row = row < N ? row : N - 1;
+        glds16(base + (int64_t)row * ldq + D + ((pl & 1) ? kcol1 : kcol0), dst + pl * 1024);
+      }
+      for (int pl = 0; pl < np; ++pl) {
+        int row = k0 + pl * 8 + lr;
+        row = row < N ? row : N - 1;
+        glds16(base + (int64_t)row * ldq + 2 * D + vcol, dst + PARTB + pl * 1024);
+      }
+    };
+    move_step(0);
+    pair_done();
+    for (int step = 0; step < nsteps; ++step) {
+      if (step + 1 < nsteps) move_step(step + 1);
+      pair_done();
+    }
+    return;
+  }
+
+  const int r = lane & 31, hh = lane >> 5;
+  const int fk = (r >> 1) & 7;
+  int koff[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) koff[s] = r * RS + (((2 * s + hh) ^ fk) * 16);
+  const int g16 = lane >> 4, li = lane & 15;
+  int voff[2];
+#pragma unroll
+  for (int d = 0; d < 2; ++d)
+    voff[d] = (4 * hh + (li >> 2)) * RS + 64 * (d ^ ((li >> 3) & 1)) + 32 * (g16 & 1) + 8 * (li & 3);
+  int ooff[4], qcol[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = 8 * i + (lane >> 3);
+    const int sw = (row >> 1) & 7;
+    ooff[i] = row * RS + (((lane & 7) ^ sw) * 16);
+    qcol[i] = ((lane & 7) ^ sw) * 8;
+  }
+  char* const qreg = smem + QBASE + wave * QREG;
+  const unsigned qreg_lds = lds0 + QBASE + wave * QREG;
+  auto issue_q = [&](int k) {   // Q rows of this wave's block of item k (nothing when the block lies past N)
+    int unit, qg;
+    item_of(k, unit, qg);
+    const int q0 = qg * CK + wave * 32;
+    if (q0 >= N) return;
+    const bf16_t* base = unit_base(unit);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      int row = q0 + 8 * j + (lane >> 3);
+      row = row < N ? row : N - 1;
+      glds16(base + (int64_t)row * ldq + qcol[j], qreg_lds + j * 1024);
+    }
+  };
+
+  uint4 ost0, ost1, ost2, ost3;
+  ost0 = ost1 = ost2 = ost3 = make_uint4(0, 0, 0, 0);
+  bf16_t* pend = nullptr;   // first row of the packed tile waiting in ost0..3 (wave-uniform), with its first query
+  int pend_q0 = 0;
+#define VITM_FLUSH_PENDING()                                                                          \
+  do {                                                                                                \
+    *(uint4*)(qreg + koff[0]) = ost0;                                                                 \
+    *(uint4*)(qreg + koff[1]) = ost1;                                                                 \
+    *(uint4*)(qreg + koff[2]) = ost2;                                                                 \
+    *(uint4*)(qreg + koff[3]) = ost3;                                                                 \
+    wait_lds();                                                                                       \
+    const uint4 w0 = *(const uint4*)(qreg + ooff[0]), w1 = *(const uint4*)(qreg + ooff[1]);           \
+    const uint4 w2 = *(const uint4*)(qreg + ooff[2]), w3 = *(const uint4*)(qreg + ooff[3]);           \
+    wait_lds();                                                                                       \
+    bf16_t* op_ = pend + (int64_t)(lane >> 3) * ldo + (lane & 7) * 8;                                 \
+    const int qr_ = pend_q0 + (lane >> 3);                                                            \
+    if (qr_ < N) *(uint4*)op_ = w0;                                                                   \
+    if (qr_ + 8 < N) *(uint4*)(op_ + 8 * ldo) = w1;                                                   \
+    if (qr_ + 16 < N) *(uint4*)(op_ + 16 * ldo) = w2;                                                 \
+    if (qr_ + 24 < N) *(uint4*)(op_ + 24 * ldo) = w3;                                                 \
+    pend = nullptr;                                                                                   \
+  } while (0)
+
+  issue_q(0);
+  pair_done();
+
+  int step = 0;
+  for (int k = 0; k < my_items; ++k) {
+    int unit, qg;
+    item_of(k, unit, qg);
+    const int q0 = qg * CK + wave * 32;
+    const bool active = q0 < N;   // wave-uniform
+    const bool more = k + 1 < my_items;
+    if (!active) {                // no queries for this wave in this item: keep the barrier count and the Q hand-over
+      if (more) issue_q(k + 1);
+      for (int c = 0; c < nchunks; ++c, ++step) pair_done();
+      continue;
+    }
+    bf16x8_t qf[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) qf[s] = *(const bf16x8_t*)(qreg + koff[s]);
+    wait_lds();
+    // the region is free (Q is in registers): previous output through it, then the next item's Q into it
+    if (pend != nullptr) VITM_FLUSH_PENDING();
+    if (more) issue_q(k + 1);
+    f32x16_t o[2];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) o[0][e] = o[1][e] = 0.f;
+    float m_run = -1e30f, lsum = 0.f;   // lsum: this half's share of the row sum (fp32 probabilities)
+
+    // one chunk of NTC key tiles out of ring entry step & 1
+    auto chunk = [&](auto ntc_tag, int keys) {
+      constexpr int NTC = decltype(ntc_tag)::value;
+      const char* Kb = smem + (step & 1) * BUFB;
+      const char* Vb = Kb + PARTB;
+      // K fragments half a tile ahead (two of a tile's four k-steps): the registers that a whole tile ahead would
+      // take are held by O here
+      bf16x8_t kf[2][2];
+#pragma unroll
+      for (int s = 0; s < 2; ++s) kf[0][s] = *(const bf16x8_t*)(Kb + koff[s]);
+      f32x16_t sacc[NTC];
+#pragma unroll
+      for (int t = 0; t < NTC; ++t) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) sacc[t][e] = 0.f;
+#pragma unroll
+        for (int hs = 0; hs < 2; ++hs) {   // half tile hs: k-steps 2 hs, 2 hs + 1
+          const int nx = 2 * t + hs + 1;   // the next half tile
+          if (nx < 2 * NTC) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) kf[nx & 1][s] = *(const bf16x8_t*)(Kb + (nx >> 1) * 32 * RS + koff[2 * (nx & 1) + s]);
+          }
+#pragma unroll
+          for (int s = 0; s < 2; ++s)
+            sacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[hs][s], qf[2 * hs + s], sacc[t], 0, 0, 0);
+        }
+      }
+      if (NTC * 32 > keys) {   // ragged last tile of the last chunk
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int key = (NTC - 1) * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+          if (key >= keys) sacc[NTC - 1][e] = -1e30f;
+        }
+      }
+      float m = sacc[0][0];
+#pragma unroll
+      for (int t = 0; t < NTC; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) m = fmaxf(m, sacc[t][e]);
+      float m_own, m_other;
+      half_pair(m, m_own, m_other);
+      const float m_new = fmaxf(m_run, fmaxf(m_own, m_other));
+      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * sl2e);   // 0 for the first chunk
+      m_run = m_new;
+      const float mb = m_new * sl2e;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        o[0][e] *= alpha;
+        o[1][e] *= alpha;
+      }
+      lsum *= alpha;
+      bf16x8_t pb[NTC][2];
+#pragma unroll
+      for (int t = 0; t < NTC; ++t) {
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          u16x8_t pk;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const float pv = __builtin_amdgcn_exp2f(fmaf(sacc[t][8 * s2 + j], sl2e, -mb));
+            lsum += pv;
+            pk[j] = f2bf(pv);
+          }
+          pb[t][s2] = __builtin_bit_cast(bf16x8_t, pk);
+        }
+      }
+      u16x4_t vf[2][4];
+#pragma unroll
+      for (int d = 0; d < 2; ++d) {
+        vf[0][2 * d] = tr_read(Vb + voff[d]);
+        vf[0][2 * d + 1] = tr_read(Vb + voff[d] + 8 * RS);
+      }
+#pragma unroll
+      for (int ks = 0; ks < 2 * NTC; ++ks) {
+        if (ks + 1 < 2 * NTC) {
+#pragma unroll
+          for (int d = 0; d < 2; ++d) {
+            vf[(ks + 1) & 1][2 * d] = tr_read(Vb + (ks + 1) * 16 * RS + voff[d]);
+            vf[(ks + 1) & 1][2 * d + 1] = tr_read(Vb + (ks + 1) * 16 * RS + voff[d] + 8 * RS);
+          }
+        }
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+          const u16x4_t lo = vf[ks & 1][2 * d], hi = vf[ks & 1][2 * d + 1];
+          u16x8_t tv;
+          tv[0] = lo[0]; tv[1] = lo[1]; tv[2] = lo[2]; tv[3] = lo[3];
+          tv[4] = hi[0]; tv[5] = hi[1]; tv[6] = hi[2]; tv[7] = hi[3];
+          o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, tv), pb[ks >> 1][ks & 1], o[d], 0, 0, 0);
+        }
+      }
+    };
+
+    for (int c = 0; c < nchunks; ++c, ++step) {
+      if (c + 1 < nchunks) {
+        chunk(std::integral_constant<int, MAX_TILES>{}, CK);
+        pair_done();
+      } else {
+        chunk(std::integral_constant<int, NTL>{}, N - c * CK);
+        // ---- the item is complete: normalise, pack (see attn_short_kernel)
+        float ls_own, ls_other;
+        half_pair(lsum, ls_own, ls_other);
+        const float l = ls_own + ls_other;
+        const float inv = __builtin_amdgcn_rcpf(l);
+        if (WITH_LSE) {
+          if (hh == 0 && q0 + r < N) lse[(int64_t)unit * N + q0 + r] = m_run * sl2e + __log2f(l);
+        }
+#define VITM_PACK_OUT(dst, d, pq)                                                          \
+  do {                                                                                    \
+    unsigned a0 = pack_bf2(o[d][8 * pq + 0] * inv, o[d][8 * pq + 1] * inv);               \
+    unsigned a1 = pack_bf2(o[d][8 * pq + 2] * inv, o[d][8 * pq + 3] * inv);               \
+    unsigned b0 = pack_bf2(o[d][8 * pq + 4] * inv, o[d][8 * pq + 5] * inv);               \
+    unsigned b1 = pack_bf2(o[d][8 * pq + 6] * inv, o[d][8 * pq + 7] * inv);               \
+    swap32u(a0, b0);                                                                      \
+    swap32u(a1, b1);                                                                      \
+    dst = make_uint4(a0, a1, b0, b1);                                                     \
+  } while (0)
+        VITM_PACK_OUT(ost0, 0, 0);
+        VITM_PACK_OUT(ost1, 0, 1);
+        VITM_PACK_OUT(ost2, 1, 0);
+        VITM_PACK_OUT(ost3, 1, 1);
+#undef VITM_PACK_OUT
+        const int b = unit / H, h = unit - b * H;
+        pend = out + ((int64_t)b * N + q0) * ldo + h * HD;
+        pend_q0 = q0;
+        pair_done();
+      }
+    }
+  }
+  if (pend != nullptr) VITM_FLUSH_PENDING();
+#undef VITM_FLUSH_PENDING
+}
+
+template <int NTL>
+int launch_chunked(const void* qkv, int64_t ldq, void* out, int64_t ldo, int B, int N, int H, float scale, float* lse,
+                   hipStream_t st) {
+  const int nunits = B * H;
+  const int QG = (N + 32 * MAX_TILES - 1) / (32 * MAX_TILES);
+  const int64_t items = (int64_t)nunits * QG;
+  const int ncu = vitm_cu_count() & ~7;
+  int grid = (int)(items < ncu ? (items + 7) / 8 * 8 : ncu);
+  grid = grid < 8 ? 8 : grid;
+  const float sl2e = scale * 1.4426950408889634f;
+  if (lse != nullptr) {
+    auto kfn = attn_chunked_kernel<NTL, true>;
+    VITM_LDS_OPTIN(kfn, SMEM, "vitm_attention_lse");
+    hipLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3(NTH), SMEM, st, (const bf16_t*)qkv, ldq, (bf16_t*)out, ldo, N, H,
+                       sl2e, nunits, lse);
+  } else {
+    auto kfn = attn_chunked_kernel<NTL, false>;
+    VITM_LDS_OPTIN(kfn, SMEM, "vitm_attention");
+    hipLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3(NTH), SMEM, st, (const bf16_t*)qkv, ldq, (bf16_t*)out, ldo, N, H,
+                       sl2e, nunits, lse);
+  }
+  VITM_CHECK_LAUNCH("vitm_attention (chunked keys)");
+  return VITM_OK;
+}
+
+int launch_long(const void* qkv, int64_t ldq, void* out, int64_t ldo, int B, int N, int H, float scale, float* lse,
+                hipStream_t st) {
+  const int last = N - (N - 1) / (32 * MAX_TILES) * (32 * MAX_TILES);   // keys of the last chunk, 1 .. 224
+  switch ((last + 31) / 32) {
+    case 1: return launch_chunked<1>(qkv, ldq, out, ldo, B, N, H, scale, lse, st);
+    case 2: return launch_chunked<2>(qkv, ldq, out, ldo, B, N, H, scale, lse, st);
+    case 3: return launch_chunked<3>(qkv, ldq, out, ldo, B, N, H, scale, lse, st);
+    case 4: return launch_chunked<4>(qkv, ldq, out, ldo, B, N, H, scale, lse, st);
+    case 5: return launch_chunked<5>(qkv, ldq, out, ldo, B, N, H, scale, lse, st);
+    case 6: return launch_chunked<6>(qkv, ldq, out, ldo, B, N, H, scale, lse, st);
+    default: return launch_chunked<7>(qkv, ldq, out, ldo, B, N, H, scale, lse, st);
+  }
+}
+
 template <int NT>
 int launch_nt(const void* qkv, int64_t ldq, void* out, int64_t ldo, int B, int N, int H, float scale, float* lse,
               hipStream_t st) {
@@ -575,8 +902,10 @@ static int attention_impl(const void* qkv, int64_t ldqkv, void* out, int64_t ldo
   VITM_REQUIRE(((uintptr_t)qkv & 15) == 0 && ((uintptr_t)out & 15) == 0, "vitm_attention: pointers must be 16-byte aligned");
   VITM_REQUIRE(scale > 0.f, "vitm_attention: scale must be positive");
   hipStream_t st = (hipStream_t)stream;
-  if (head_dim == 64 && N <= 32 * short_seq::MAX_TILES && (int64_t)B * H < (1ll << 31))
-    return short_seq::launch(qkv, ldqkv, out, ldo, B, N, H, scale, lse, st);
+  if (head_dim == 64 && (int64_t)B * H < (1ll << 28)) {
+    if (N <= 32 * short_seq::MAX_TILES) return short_seq::launch(qkv, ldqkv, out, ldo, B, N, H, scale, lse, st);
+    return short_seq::launch_long(qkv, ldqkv, out, ldo, B, N, H, scale, lse, st);
+  }
   switch (head_dim) {
     case 32: return launch_attn<32>(qkv, ldqkv, out, ldo, B, N, H, scale, lse, st);
     case 64: return launch_attn<64>(qkv, ldqkv, out, ldo, B, N, H, scale, lse, st);

@@ -274,6 +274,21 @@ __global__ __launch_bounds__(NT, 2) void gemm_pp_kernel(const GemmArgs p) {
     }
     return n;
   };
+  // first / second half of the next A K-tile (pieces 0-1 / 2-3); the second call advances the stream
+  auto issueA_half = [&](int half) -> int {
+    if (a_it >= ntl) return 0;
+    char* sb = smem + a_slot * PART + 4 * wave * 1024;
+    glds16(asrc[2 * half] + a_t * BK, sb + (2 * half) * 1024);
+    glds16(asrc[2 * half + 1] + a_t * BK, sb + (2 * half + 1) * 1024);
+    if (half == 1) {
+      a_slot = a_slot == NA - 1 ? 0 : a_slot + 1;
+      if (++a_t == nk) {
+        a_t = 0;
+        if (++a_it < ntl) set_a(a_it);
+      }
+    }
+    return 2;
+  };
   auto issueW = [&]() {
     if (w_it >= ntl) return;
     char* sb = smem + WBASE + w_slot * PART + 4 * wave * 1024;
@@ -345,7 +360,11 @@ __global__ __launch_bounds__(NT, 2) void gemm_pp_kernel(const GemmArgs p) {
     for (int t = 0; t < nk; ++t) {
       // ---- L(t,0)
       load_frags(0);
+#if (PP_ABLATE & 8)
+      issueA_half(0);
+#else
       if (dma) issueW();           // W(g+1)
+#endif
       wait_lds();
       seg_barrier();
       // ---- C(t,0)
@@ -353,7 +372,11 @@ __global__ __launch_bounds__(NT, 2) void gemm_pp_kernel(const GemmArgs p) {
       seg_barrier();
       // ---- L(t,1)
       load_frags(1);
+#if (PP_ABLATE & 8)
+      const int keep = 2 * issueA_half(1);
+#else
       const int keep = dma ? issueA() : 0;   // A(g+2)
+#endif
       wait_lds();
       if (grp == 1) wait_dma(keep);   // group 1: its L(t,1) IS segment 3
       seg_barrier();
