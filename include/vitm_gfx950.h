@@ -215,6 +215,22 @@ int vitm_scale_channels(const void* x, int64_t ldx, void* out, int64_t ldo, int 
  */
 int vitm_gelu(const void* x, int64_t ldx, void* out, int64_t ldo, int dtype, int M, int D, vitm_stream_t stream);
 
+/*
+ * out = act(x) elementwise for an MLP built with an activation other than the exact GELU (MLP's act_layer argument,
+ * models.py:106,122: the reference instantiates whatever class it is given).  x, out as in vitm_gelu (may alias).
+ * The exact GELU stays fused in the fc1 epilogue; these run as a pass of their own between the two GEMMs.
+ */
+enum vitm_activation_kind {
+  VITM_ACT_GELU_ERF = 0, /* nn.GELU()                   */
+  VITM_ACT_RELU = 1,     /* nn.ReLU()                   */
+  VITM_ACT_GELU_TANH = 2,/* nn.GELU(approximate="tanh") */
+  VITM_ACT_SILU = 3,     /* nn.SiLU()                   */
+  VITM_ACT_SIGMOID = 4,  /* nn.Sigmoid()                */
+  VITM_ACT_TANH = 5      /* nn.Tanh()                   */
+};
+int vitm_activation(const void* x, int64_t ldx, void* out, int64_t ldo, int dtype, int M, int D, int kind,
+                    vitm_stream_t stream);
+
 /* dst (bf16) <- src (f32), n elements; used to bring fp32 images/activations onto the bf16 path. */
 int vitm_cast_f32_to_bf16(const float* src, void* dst, int64_t n, vitm_stream_t stream);
 /* dst (f32) <- src (bf16), n elements. */

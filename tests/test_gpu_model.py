@@ -190,6 +190,53 @@ def test_standalone_modules_match_torch():
         assert rel_err(ls(xh).cpu(), (xb * 0.5).cpu()) < 1e-2
 
 
+@pytest.mark.parametrize("act", [nn.ReLU, nn.SiLU, nn.Sigmoid, nn.Tanh, lambda: nn.GELU(approximate="tanh")])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_mlp_other_activations_and_conv_form(act, dtype):
+    """MLP with the activations the library has a kernel for besides the fused exact GELU, as Linear layers on
+    tokens and as 1x1 convolutions on an NCHW map (models.py:106,119,122), against the same modules in torch."""
+    from vitm_amd.models.models import MLP
+    torch.manual_seed(1)
+    F = torch.nn.functional
+    tol = 3e-2 if dtype == torch.bfloat16 else 1e-4
+    mlp = MLP(192, 384, bias=True, act_layer=act).cuda()
+    x = torch.randn(3, 50, 192, device="cuda")
+    xq = x.to(dtype).float()
+    with torch.no_grad():
+        ref = mlp.linear_layer2(mlp.ac1(mlp.linear_layer1(xq)))
+        got = mlp.to(dtype)(x.to(dtype))
+    assert got.dtype == dtype and rel_err(got.cpu(), ref.cpu()) < tol
+    conv = MLP(64, 128, bias=True, act_layer=act, use_conv=True).cuda()
+    xi = torch.randn(2, 64, 9, 7, device="cuda")
+    xiq = xi.to(dtype).float()
+    with torch.no_grad():
+        ref = conv.linear_layer2(conv.ac1(conv.linear_layer1(xiq)))
+        got = conv.to(dtype)(xi.to(dtype))
+    assert got.shape == ref.shape and rel_err(got.cpu(), ref.cpu()) < tol
+    with pytest.raises(NotImplementedError):
+        MLP(64, 128, act_layer=nn.Softplus).cuda()(xi[:, :, 0, 0])
+
+
+def test_layernorm_without_affine():
+    """norm_layer=partial(nn.LayerNorm, elementwise_affine=False) (models.py:181,189): unit weight / zero bias stand in."""
+    from functools import partial
+    from vitm_amd.models.models import Block
+    torch.manual_seed(2)
+    LNP = partial(nn.LayerNorm, elementwise_affine=False)
+    blk = Block(128, 2, 2.0, norm_layer=LNP).cuda().eval()
+    with torch.no_grad():
+        blk.ls1.gamma.fill_(0.7)
+        blk.ls2.gamma.fill_(1.1)
+        x = torch.randn(2, 33, 128, device="cuda")
+        F = torch.nn.functional
+        h = F.layer_norm(x, (128,))
+        qkv = blk.attn.qkv(h).reshape(2, 33, 3, 2, 64).permute(2, 0, 3, 1, 4)
+        a = ((qkv[0] * 64 ** -0.5) @ qkv[1].transpose(-2, -1)).softmax(-1) @ qkv[2]
+        y = x + 0.7 * blk.attn.proj(a.transpose(1, 2).reshape(2, 33, 128))
+        ref = y + 1.1 * blk.mlp.linear_layer2(F.gelu(blk.mlp.linear_layer1(F.layer_norm(y, (128,)))))
+        assert rel_err(blk(x).cpu(), ref.cpu()) < 1e-4
+
+
 def test_batch_independence_and_determinism():
     """Images are independent: a batch equals its halves run separately (the multi-GPU sharding invariant),
     and two runs are bit-identical."""

@@ -313,6 +313,31 @@ __global__ __launch_bounds__(256) void gelu_kernel(const T* __restrict__ x, int6
   }
 }
 
+// out = act(x) elementwise for the activations an MLP may be built with besides the fused erf GELU
+template <typename T, int KIND>
+__global__ __launch_bounds__(256) void activation_kernel(const T* __restrict__ x, int64_t ldx, T* __restrict__ out,
+                                                         int64_t ldo, int M, int D) {
+  const int cpr = D / 8;
+  const int64_t total = (int64_t)M * cpr;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t m = i / cpr;
+    const int c = (int)(i - m * cpr) * 8;
+    float v[8];
+    load8<T>(x + m * ldx + c, v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float t = v[e];
+      if (KIND == VITM_ACT_RELU) v[e] = fmaxf(t, 0.f);
+      else if (KIND == VITM_ACT_GELU_TANH) v[e] = 0.5f * t * (1.f + tanhf(0.7978845608028654f * (t + 0.044715f * t * t * t)));
+      else if (KIND == VITM_ACT_SILU) v[e] = t / (1.f + __expf(-t));
+      else if (KIND == VITM_ACT_SIGMOID) v[e] = 1.f / (1.f + __expf(-t));
+      else if (KIND == VITM_ACT_TANH) v[e] = tanhf(t);
+      else v[e] = gelu_erf_accurate(t);
+    }
+    store8(out + m * ldo + c, v);
+  }
+}
+
 __device__ __forceinline__ float block_sum_256(float v, float* sh) {
   v = wave_sum(v);
   __syncthreads();
@@ -500,6 +525,38 @@ extern "C" int vitm_gelu(const void* x, int64_t ldx, void* out, int64_t ldo, int
     hipLaunchKernelGGL(gelu_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)x, ldx, (float*)out, ldo, M, D);
   }
   VITM_CHECK_LAUNCH("vitm_gelu");
+  return VITM_OK;
+}
+
+template <int KIND>
+static void launch_activation(const void* x, int64_t ldx, void* out, int64_t ldo, int dtype, int M, int D, hipStream_t st) {
+  const dim3 grid(stream_grid((int64_t)M * (D / 8)));
+  if (dtype == VITM_BF16) {
+    hipLaunchKernelGGL((activation_kernel<bf16_t, KIND>), grid, dim3(256), 0, st, (const bf16_t*)x, ldx, (bf16_t*)out, ldo, M, D);
+  } else {
+    hipLaunchKernelGGL((activation_kernel<float, KIND>), grid, dim3(256), 0, st, (const float*)x, ldx, (float*)out, ldo, M, D);
+  }
+}
+
+extern "C" int vitm_activation(const void* x, int64_t ldx, void* out, int64_t ldo, int dtype, int M, int D, int kind,
+                               vitm_stream_t stream) {
+  VITM_REQUIRE(x && out, "vitm_activation: null pointer");
+  VITM_REQUIRE(dtype == VITM_BF16 || dtype == VITM_F32, "vitm_activation: bad dtype %d", dtype);
+  VITM_REQUIRE(M > 0 && D > 0 && D % 8 == 0 && ldx >= D && ldo >= D && ldx % 8 == 0 && ldo % 8 == 0, "vitm_activation: D/ld must be multiples of 8");
+  VITM_REQUIRE(al16(x) && al16(out), "vitm_activation: pointers must be 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  switch (kind) {
+    case VITM_ACT_GELU_ERF: launch_activation<VITM_ACT_GELU_ERF>(x, ldx, out, ldo, dtype, M, D, st); break;
+    case VITM_ACT_RELU: launch_activation<VITM_ACT_RELU>(x, ldx, out, ldo, dtype, M, D, st); break;
+    case VITM_ACT_GELU_TANH: launch_activation<VITM_ACT_GELU_TANH>(x, ldx, out, ldo, dtype, M, D, st); break;
+    case VITM_ACT_SILU: launch_activation<VITM_ACT_SILU>(x, ldx, out, ldo, dtype, M, D, st); break;
+    case VITM_ACT_SIGMOID: launch_activation<VITM_ACT_SIGMOID>(x, ldx, out, ldo, dtype, M, D, st); break;
+    case VITM_ACT_TANH: launch_activation<VITM_ACT_TANH>(x, ldx, out, ldo, dtype, M, D, st); break;
+    default:
+      vitm_set_error("vitm_activation: unknown activation kind %d", kind);
+      return VITM_EINVAL;
+  }
+  VITM_CHECK_LAUNCH("vitm_activation");
   return VITM_OK;
 }
 

@@ -16,6 +16,7 @@ LIB_PATH = os.environ.get(
 
 BF16, F32 = 0, 1
 STATS_PARTS = 4   # VITM_STATS_PARTS
+ACT_GELU_ERF, ACT_RELU, ACT_GELU_TANH, ACT_SILU, ACT_SIGMOID, ACT_TANH = range(6)   # enum vitm_activation_kind
 EPI_BIAS, EPI_BIAS_GELU, EPI_LN, EPI_LN_GELU, EPI_RESIDUAL, EPI_DGELU = 0, 1, 2, 3, 4, 5
 
 
@@ -62,6 +63,7 @@ SIGNATURES = {
     "vitm_residual_scale": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int, c_int, c_int,
                                     c_void_p]),
     "vitm_gelu": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
+    "vitm_activation": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p]),
     "vitm_attention_f32_lse": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int, c_int, c_int, c_int, c_float,
                                        c_void_p]),
     "vitm_attention_bwd_f32": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64,

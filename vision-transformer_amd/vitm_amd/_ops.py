@@ -260,6 +260,24 @@ def gelu(x: torch.Tensor, out: torch.Tensor, M: int, D: int) -> None:
     _lib.check(_lib.load().vitm_gelu(_p(x), x.stride(0), _p(out), out.stride(0), _dt(x), M, D, _stream()), "vitm_gelu")
 
 
+def activation_kind(act) -> Optional[int]:
+    """enum vitm_activation_kind of an activation module, or None when the library has no kernel for it."""
+    import torch.nn as nn
+    if isinstance(act, nn.GELU):
+        approx = getattr(act, "approximate", "none")
+        return _lib.ACT_GELU_ERF if approx == "none" else (_lib.ACT_GELU_TANH if approx == "tanh" else None)
+    for cls, kind in ((nn.ReLU, _lib.ACT_RELU), (nn.SiLU, _lib.ACT_SILU), (nn.Sigmoid, _lib.ACT_SIGMOID), (nn.Tanh, _lib.ACT_TANH)):
+        if type(act) is cls:
+            return kind
+    return None
+
+
+def activation(x: torch.Tensor, out: torch.Tensor, M: int, D: int, kind: int) -> None:
+    assert x.dtype == out.dtype
+    _lib.check(_lib.load().vitm_activation(_p(x), x.stride(0), _p(out), out.stride(0), _dt(x), M, D, kind, _stream()),
+               "vitm_activation")
+
+
 def to_bf16(x: torch.Tensor) -> torch.Tensor:
     """A contiguous bf16 copy of a contiguous fp32/bf16 CUDA tensor (cast kernel, not torch)."""
     x = x.contiguous()

@@ -145,7 +145,9 @@ class MLP(nn.Module):
 
     As in the reference, ``out_features`` is ignored (the output width is ``in_features``), ``bias`` may be a
     bool or a pair, and ``norm_layer`` / ``vit`` are accepted and unused.  ``use_conv=True`` builds the 1x1
-    Conv2d layers (same parameter shapes) but that variant has no HIP forward.
+    Conv2d layers (models.py:119) and takes (B, C, H, W) input: a 1x1 convolution is the same GEMM on
+    ``weight.view(out, in)`` over the pixels as rows.  The exact GELU is fused into the first GEMM's epilogue; ReLU,
+    tanh-GELU, SiLU, Sigmoid and Tanh run as one elementwise pass between the two GEMMs (``vitm_activation``).
     """
 
     def __init__(self, in_features, hidden_features: int = None, out_features: int = None, use_conv: bool = False,
@@ -169,25 +171,50 @@ class MLP(nn.Module):
     def _fc2_pack(self, dtype, gamma=None) -> _ops.PackedLinear:
         return _pack(self, "fc2", dtype, self.linear_layer2.weight, self.linear_layer2.bias, gamma=gamma)
 
+    def _act_kind(self) -> int:
+        kind = _ops.activation_kind(self.ac1)
+        if kind is None:
+            raise NotImplementedError(f"MLP: no kernel for activation {self.ac1!r} (nn.GELU exact or tanh, nn.ReLU, "
+                                      f"nn.SiLU, nn.Sigmoid, nn.Tanh)")
+        return kind
+
     def _check(self):
-        if self.use_conv:
-            raise NotImplementedError("MLP(use_conv=True) has no HIP forward")
-        _check_gelu(self.ac1, "MLP")
+        self._act_kind()
+
+    def _fc1(self, xb: torch.Tensor, pk, h: torch.Tensor, M: int, ln_epilogue: bool = False, **stats) -> None:
+        """First GEMM + activation into h: the exact GELU in the GEMM's epilogue, any other activation as a pass over h."""
+        kind = self._act_kind()
+        fused = kind == _ops._lib.ACT_GELU_ERF
+        if ln_epilogue:
+            epi = _ops.EPI_LN_GELU if fused else _ops.EPI_LN
+        else:
+            epi = _ops.EPI_BIAS_GELU if fused else _ops.EPI_BIAS
+        _ops.gemm(xb, pk, h, epi, M, **stats)
+        if not fused:
+            _ops.activation(h, h, M, pk.npad, kind)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        """(..., in_features) -> (..., in_features)."""
+        """(..., in_features) -> (..., in_features); with ``use_conv=True``: (B, C, H, W) -> (B, C, H, W)."""
         _ops.require_cuda(x, "MLP.forward")
         self._check()
         C = self.in_features
+        if self.use_conv:
+            if x.dim() != 4 or x.shape[1] != C:
+                raise RuntimeError(f"MLP(use_conv=True) takes (B, {C}, H, W) input, got {tuple(x.shape)}")
+            rows = x.permute(0, 2, 3, 1)          # pixels as rows (a layout copy, no arithmetic)
+            lead = rows.shape[:-1]
+        else:
+            rows, lead = x, x.shape[:-1]
         with torch.cuda.device(x.device):
-            xb, M = _as_rows(x, C)
+            xb, M = _as_rows(rows, C)
             dt = xb.dtype
             p1, p2 = self._fc1_pack(dt), self._fc2_pack(dt)
             h = _act_buffer(M, self.hidden_features, x.device, dt, zero_pad_from=p1.npad)
-            _ops.gemm(xb, p1, h, _ops.EPI_BIAS_GELU, M)
+            self._fc1(xb, p1, h, M)
             y = torch.empty((M, p2.npad), dtype=dt, device=x.device)
             _ops.gemm(h, p2, y, _ops.EPI_BIAS, M)
-            return y[:, :self.out_features].reshape(*x.shape[:-1], self.out_features)
+            y = y[:, :self.out_features].reshape(*lead, self.out_features)
+            return y.permute(0, 3, 1, 2).contiguous() if self.use_conv else y
 
 
 Mlp = MLP  # timm spelling
@@ -287,15 +314,15 @@ class Block(nn.Module):
         _ops.gemm(ws["o"], proj_pk, x2d, _ops.EPI_RESIDUAL, M, resid=x2d, stats_out=ws["carried"] if carry else None)
         # MLP branch
         if ln2 is None:
-            _ops.gemm(x2d, mlp._fc1_pack(dt), ws["h"], _ops.EPI_BIAS_GELU, M)
+            mlp._fc1(x2d, mlp._fc1_pack(dt), ws["h"], M)
         elif f32:
-            _ops.gemm(normed(ln2), mlp._fc1_pack(dt), ws["h"], _ops.EPI_BIAS_GELU, M)
+            mlp._fc1(normed(ln2), mlp._fc1_pack(dt), ws["h"], M)
         elif carry:
-            _ops.gemm(x2d, mlp._fc1_pack(dt, ln2), ws["h"], _ops.EPI_LN_GELU, M, stats=ws["carried"], stats_partial=True,
-                      ln_eps=ln2[2])
+            mlp._fc1(x2d, mlp._fc1_pack(dt, ln2), ws["h"], M, ln_epilogue=True, stats=ws["carried"], stats_partial=True,
+                     ln_eps=ln2[2])
         else:
             _ops.ln_stats(x2d, M, D, ln2[2], ws["stats"])
-            _ops.gemm(x2d, mlp._fc1_pack(dt, ln2), ws["h"], _ops.EPI_LN_GELU, M, stats=ws["stats"])
+            mlp._fc1(x2d, mlp._fc1_pack(dt, ln2), ws["h"], M, ln_epilogue=True, stats=ws["stats"])
         _ops.gemm(ws["h"], fc2_pk, x2d, _ops.EPI_RESIDUAL, M, resid=x2d, stats_out=ws["carried"] if carry else None)
         ws["carried_valid"] = carry
 

@@ -20,8 +20,18 @@ def layernorm_params(mod: nn.Module, what: str):
     """(weight, bias, eps) of an affine nn.LayerNorm, or None for nn.Identity; anything else is refused."""
     if isinstance(mod, nn.Identity):
         return None
-    if isinstance(mod, nn.LayerNorm) and mod.elementwise_affine and len(mod.normalized_shape) == 1:
-        return mod.weight, mod.bias, mod.eps
+    if isinstance(mod, nn.LayerNorm) and len(mod.normalized_shape) == 1:
+        if mod.elementwise_affine and mod.bias is not None:
+            return mod.weight, mod.bias, mod.eps
+        # no affine (or no bias): unit weight / zero bias stand in, kept on the module, on the device of `like`
+        like = mod.weight if mod.weight is not None else None
+        dev = like.device if like is not None else getattr(mod, "_vitm_device", None)
+        unit = getattr(mod, "_vitm_unit", None)
+        if unit is None or (dev is not None and unit[0].device != dev):
+            dev = dev if dev is not None else torch.device("cuda", torch.cuda.current_device())
+            unit = (torch.ones(mod.normalized_shape[0], device=dev), torch.zeros(mod.normalized_shape[0], device=dev))
+            object.__setattr__(mod, "_vitm_unit", unit)
+        return (mod.weight if mod.weight is not None else unit[0]), unit[1], mod.eps
     raise NotImplementedError(f"{what}: only nn.LayerNorm (affine, last dim) or nn.Identity run on the HIP path, "
                               f"got {type(mod).__name__}")
 

@@ -77,7 +77,9 @@ def supported(model) -> Optional[str]:
         if type(blk) is not Block:
             return f"block type {type(blk).__name__} has no backward"
         if blk.mlp.use_conv:
-            return "MLP(use_conv=True) has no HIP path"
+            return "MLP(use_conv=True) has no backward"
+        if _ops.activation_kind(blk.mlp.ac1) != _ops._lib.ACT_GELU_ERF:
+            return "the backward implements the exact GELU only"
     return None
 
 
