@@ -6,8 +6,9 @@ import torch, numpy as np
 from vitm_amd import _ops as ops, _lib
 lib = _lib.load()
 M = 50432
+PA = int(os.environ.get("PAD_A", "0")); PW = int(os.environ.get("PAD_W", "0"))   # extra elements of row pitch
 def stamp(name, N, K, epi):
-    A = torch.randn(M, K, device="cuda").to(torch.bfloat16)
+    A = torch.randn(M, K + PA, device="cuda").to(torch.bfloat16)[:, :K]
     W = torch.randn(N, K, device="cuda") * K ** -0.5
     b = torch.randn(N, device="cuda") * 0.1
     if epi in (ops.EPI_LN, ops.EPI_LN_GELU):
@@ -15,10 +16,13 @@ def stamp(name, N, K, epi):
         stats = ops.ln_stats(A, M, K, 1e-5)
     else:
         pk = ops.pack_linear(W, b); stats = None
+    wp = pk.wp
+    if PW:
+        wp = torch.zeros((pk.wp.shape[0], pk.kpad + PW), dtype=pk.wp.dtype, device="cuda"); wp[:, :pk.kpad] = pk.wp
     out = torch.empty((M, N), dtype=torch.bfloat16, device="cuda")
     dbg = torch.zeros((256, 12, 8), dtype=torch.int64, device="cuda")
     def run():
-        _lib.check(lib.vitm_gemm(ops._p(A), K, ops._p(pk.wp), pk.kpad, ops._p(out), N, 0, M, N, K, epi, ops._p(stats), ops._p(pk.s), ops._p(pk.c), None, ops._p(dbg), N, 0, ops._stream()), "gemm")
+        _lib.check(lib.vitm_gemm(ops._p(A), K + PA, ops._p(wp), pk.kpad + PW, ops._p(out), N, 0, M, N, K, epi, ops._p(stats), ops._p(pk.s), ops._p(pk.c), None, ops._p(dbg), N, 0, ops._stream()), "gemm")
     for _ in range(20): run()
     torch.cuda.synchronize()
     d = dbg.cpu().numpy().astype("float64")
@@ -31,7 +35,7 @@ def stamp(name, N, K, epi):
     gap = d[:, 1:nt, 0] - d[:, :nt-1, 2]
     k0 = d[:, :nt, 4] - d[:, :nt, 0]; k1 = d[:, :nt, 5] - d[:, :nt, 4]; k2 = d[:, :nt, 6] - d[:, :nt, 5]
     rest = (d[:, :nt, 1] - d[:, :nt, 6]) / (K // 64 - 3)
-    print(f"== {name} N={N} K={K} epi={epi} tiles={tiles} whole rounds stamped={nt}")
+    print(f"== pad A {PA} W {PW} {name} N={N} K={K} epi={epi} tiles={tiles} whole rounds stamped={nt}")
     print("median K-loop cycles per tile index:", np.median(ml, 0).astype(int))
     print("median epilogue cycles per tile index:", np.median(ep, 0).astype(int))
     print("K-tile 0 / 1 / 2 / mean of the rest (median cycles):", np.median(k0, 0).astype(int), np.median(k1, 0).astype(int), np.median(k2, 0).astype(int), np.median(rest, 0).astype(int))
