@@ -267,7 +267,8 @@ def test_patch_embed(ops, img, p, D, B, dtype):
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("img,p,D,B", [(224, 16, 768, 160), (64, 8, 256, 520), (60, 6, 256, 400)])
 def test_patch_embed_large_batch_route(ops, img, p, D, B, dtype):
-    """Batches large enough for the patch-matrix pass + big-tile GEMM route (vector and element-wise gathers)."""
+    """Batches large enough for the big-tile GEMM: bf16 images with a power-of-two patch width are gathered by the
+    kernel's own loader, everything else goes through the patch-matrix pass (vector and element-wise gathers)."""
     from oracle import vit_oracle as O
     from vitm_amd import _lib
     x = (_rand(B, 3, img, img, seed=60)).to(dtype)
@@ -282,12 +283,23 @@ def test_patch_embed_large_batch_route(ops, img, p, D, B, dtype):
         ops.patch_embed(x, pk, tok, (p, p), D, cls_slot)
         got = tok.view(B, Np + int(cls_slot), D)
         if cls_slot:
-            _close(got[:, 0], b.expand(B, D), what="class-token slot holds the bias until embed_finalize")
+            if dtype == torch.bfloat16 and p & (p - 1) == 0:   # gathered inside the big-tile kernel: the slot is not written
+                assert (got[:, 0] == 7.0).all(), "class-token slot must be left untouched"
+            else:                         # patch-matrix route: the slot's patch row is zero, so it holds the bias
+                _close(got[:, 0], b.expand(B, D), what="class-token slot holds the bias until embed_finalize")
             got = got[:, 1:]
         for lo in range(0, B, 64):   # chunked reference
             cols = O.im2col(x[lo:lo + 64].to(torch.bfloat16).float().cpu(), (p, p)).to(DEV)
             ref = cols @ _bf(w).float().reshape(D, -1).t() + b
             _close(got[lo:lo + 64], ref, what="patch embed (large batch)")
+        if dtype == torch.bfloat16 and p & (p - 1) == 0:
+            # the gathering loader feeds the same kernel the same operands in the same order as the patch-matrix route
+            A = torch.empty((rows, pk.kpad), dtype=torch.bfloat16, device=DEV)
+            ops.im2col(x, A, (p, p), pk.kpad, cls_slot)
+            tok2 = torch.empty((rows, D), dtype=torch.bfloat16, device=DEV)
+            ops.gemm(A, pk, tok2, ops.EPI_BIAS, rows)
+            got2 = tok2.view(B, Np + int(cls_slot), D)[:, int(cls_slot):]
+            assert torch.equal(got, got2), "gathered and patch-matrix routes differ"
 
 
 def test_embed_finalize_and_layernorm(ops):

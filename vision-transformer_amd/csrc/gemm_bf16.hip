@@ -331,6 +331,16 @@ extern "C" int vitm_patch_embed(const void* img, int img_dtype, int B, int C, in
   a.img = img; a.C = C; a.H = H; a.Wd = W; a.ph = ph; a.gw = gw; a.npatch = gh * gw; a.kreal = kreal;
   a.pw = pw;
   a.vec = vec_ok ? 1 : 0;  // otherwise the loader gathers element by element
+  // large batch, bf16 image, power-of-two patch width: the 256x256 persistent kernel with the gather in its DMA
+  // addresses (no patch matrix in memory).  Its rows include the class-token slots, so the row map is the identity.
+  const int rows = B * (gh * gw + (cls_slot ? 1 : 0));
+  if (img_dtype == VITM_BF16 && vec_ok && kreal == kpad && (pw & (pw - 1)) == 0 && pw <= BK &&
+      vitm_gemm_pp_wanted(rows, D, kpad) && (int64_t)B * C * H * W < (1ll << 31)) {
+    GemmArgs b = a;
+    b.M = rows; b.row_group = 0; b.cls = cls_slot ? 1 : 0;
+    b.pw_shift = __builtin_ctz((unsigned)pw);
+    return vitm_gemm_pp_launch(b, VITM_EPI_BIAS, (hipStream_t)stream);
+  }
   if (img_dtype == VITM_F32) return launch<VITM_EPI_BIAS, A_IM2COL_F32, 0>(a, (hipStream_t)stream);
   return launch<VITM_EPI_BIAS, A_IM2COL_BF16, 0>(a, (hipStream_t)stream);
 }

@@ -27,9 +27,11 @@ struct GemmArgs {
   float* stats_out;
   int stats_partial;
   float ln_inv_dim, ln_eps;
-  // im2col source (patch embedding)
+  // im2col source (patch embedding).  Big-tile kernel: img != nullptr selects the gathering loader; rows are
+  // (image, token) with `cls` leading class-token slots per image, pw = 1 << pw_shift
   const void* img;
   int C, H, Wd, ph, pw, gw, npatch, kreal, vec;
+  int cls, pw_shift;
 };
 
 __device__ __forceinline__ void glds16(const void* g, void* l) {

@@ -157,7 +157,11 @@ __host__ __device__ inline Deal deal_tiles(int T, int nwg, int xg, bool share, i
 // SLICE = false: NBLK = 8, whole tiles (p.share: the leftover tiles are left to the SLICE launch).
 // SLICE = true:  one slice of NBLK 16-row blocks (of both wave groups) of one leftover tile per workgroup.
 // STATS (RESIDUAL epilogue only): also write the per-row raw moments of this tile's output values (p.stats_out).
-template <int EPI, int NBLK, bool SLICE, bool STATS = false>
+// IM2COL (patch embedding): the A operand is never materialised -- row m of A is patch (or class-token slot) m of the
+// NCHW bf16 image batch p.img and the DMA gathers it: a lane's 16-byte chunk is 8 consecutive pixels of one patch row
+// (patch width a power of two >= 8, so a chunk never straddles patch rows and the pixel column of a lane is the same in
+// every K-tile); from one K-tile to the next a lane moves down 64 / pw image rows, wrapping into the next channel.
+template <int EPI, int NBLK, bool SLICE, bool STATS = false, bool IM2COL = false>
 __global__ __launch_bounds__(NT, 2) void gemm_pp_kernel(const GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -223,6 +227,18 @@ __global__ __launch_bounds__(NT, 2) void gemm_pp_kernel(const GemmArgs p) {
     a_hi = fa + 1 < i0 + NBLK ? 4 : (fa < i0 + NBLK ? 2 : 0);
     a_hi = a_hi < a_lo ? a_lo : a_hi;
   }
+  // IM2COL: this lane's pixel offset inside a patch-row-major K index, at K-tile 0 (ky0 rows down, channel folded in)
+  // and as the A stream advances (a_ky, a_koff)
+  int ky0 = 0, koff0 = 0, a_ky = 0, a_koff = 0;
+  const int kstep = IM2COL ? (BK >> p.pw_shift) : 0;           // image rows per K-tile
+  if (IM2COL) {
+    ky0 = (lc * 8) >> p.pw_shift;
+    koff0 = ky0 * p.Wd + ((lc * 8) & (p.pw - 1));
+    while (ky0 >= p.ph) {
+      ky0 -= p.ph;
+      koff0 += (p.H - p.ph) * p.Wd;
+    }
+  }
   auto set_a = [&](int it) {
     int mt, nt;
     tile_mn(tile_of(it), mt, nt);
@@ -231,7 +247,26 @@ __global__ __launch_bounds__(NT, 2) void gemm_pp_kernel(const GemmArgs p) {
     for (int q = 0; q < 4; ++q) {
       int am = am0 + (4 * wave + q) * 8 + lr;
       am = am < p.M ? am : p.M - 1;
-      asrc[q] = p.A + (int64_t)am * p.lda + lc * 8;
+      if (!IM2COL) {
+        asrc[q] = p.A + (int64_t)am * p.lda + lc * 8;
+      } else {
+        const int ntok = p.npatch + p.cls;
+        const int b = am / ntok;
+        int t = am - b * ntok - p.cls;       // a class-token slot reads patch 0; its output row is not stored
+        t = t < 0 ? 0 : t;
+        const int py = t / p.gw, px = t - py * p.gw;
+        asrc[q] = (const bf16_t*)p.img + (((int64_t)b * p.C * p.H + py * p.ph) * p.Wd + px * p.pw);
+      }
+    }
+    a_ky = ky0;
+    a_koff = koff0;
+  };
+  auto advance_a_k = [&]() {   // IM2COL: one K-tile further down the patch
+    a_ky += kstep;
+    a_koff += kstep * p.Wd;
+    while (a_ky >= p.ph) {
+      a_ky -= p.ph;
+      a_koff += (p.H - p.ph) * p.Wd;
     }
   };
   auto set_w = [&](int it) {
@@ -252,25 +287,28 @@ __global__ __launch_bounds__(NT, 2) void gemm_pp_kernel(const GemmArgs p) {
   auto issueA = [&]() -> int {   // returns the number of pieces issued
     if (a_it >= ntl) return 0;
     char* sb = smem + a_slot * PART + 4 * wave * 1024;
+    const int ao = IM2COL ? a_koff : a_t * BK;
     int n = 4;
     if (!SLICE) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) glds16(asrc[q] + a_t * BK, sb + q * 1024);
+      for (int q = 0; q < 4; ++q) glds16(asrc[q] + ao, sb + q * 1024);
     } else {
       n = a_hi - a_lo;
       if (a_lo == 0 && n >= 2) {
-        glds16(asrc[0] + a_t * BK, sb);
-        glds16(asrc[1] + a_t * BK, sb + 1024);
+        glds16(asrc[0] + ao, sb);
+        glds16(asrc[1] + ao, sb + 1024);
       }
       if (a_hi == 4 && n >= 2) {
-        glds16(asrc[2] + a_t * BK, sb + 2048);
-        glds16(asrc[3] + a_t * BK, sb + 3072);
+        glds16(asrc[2] + ao, sb + 2048);
+        glds16(asrc[3] + ao, sb + 3072);
       }
     }
     a_slot = a_slot == NA - 1 ? 0 : a_slot + 1;
     if (++a_t == nk) {
       a_t = 0;
       if (++a_it < ntl) set_a(a_it);
+    } else if (IM2COL) {
+      advance_a_k();
     }
     return n;
   };
@@ -467,8 +505,14 @@ __global__ __launch_bounds__(NT, 2) void gemm_pp_kernel(const GemmArgs p) {
         if (stores_on && nst < p.N && (!SLICE || (i0 + i >= is0 && i0 + i < is1))) {
           const int m1 = mst + 16 * i, m2 = m1 + 8;
           bf16_t* o = (bf16_t*)p.out + (int64_t)m1 * p.ldo + nst;
-          if (m1 < p.M) store_out(o, a0, b0, c0, d0);
-          if (m2 < p.M) store_out(o + 8 * p.ldo, a1, b1, c1, d1);
+          if (!IM2COL || p.cls == 0) {
+            if (m1 < p.M) store_out(o, a0, b0, c0, d0);
+            if (m2 < p.M) store_out(o + 8 * p.ldo, a1, b1, c1, d1);
+          } else {   // rows that are class-token slots are left untouched
+            const int ntok = p.npatch + 1;
+            if (m1 < p.M && m1 % ntok != 0) store_out(o, a0, b0, c0, d0);
+            if (m2 < p.M && m2 % ntok != 0) store_out(o + 8 * p.ldo, a1, b1, c1, d1);
+          }
         }
       }
     } else {
@@ -616,9 +660,9 @@ __global__ __launch_bounds__(NT, 2) void gemm_pp_kernel(const GemmArgs p) {
   }
 }
 
-template <int EPI, int NBLK, bool SLICE, bool STATS = false>
+template <int EPI, int NBLK, bool SLICE, bool STATS = false, bool IM2COL = false>
 int launch_one(const GemmArgs& b, int grid, hipStream_t st) {
-  auto kfn = gemm_pp_kernel<EPI, NBLK, SLICE, STATS>;
+  auto kfn = gemm_pp_kernel<EPI, NBLK, SLICE, STATS, IM2COL>;
   VITM_LDS_OPTIN(kfn, SMEM, "vitm_gemm");
   hipLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3(NT), SMEM, st, b);
   VITM_CHECK_LAUNCH("vitm_gemm (256x256 tile)");
@@ -671,6 +715,17 @@ int launch(const GemmArgs& a, hipStream_t st) {
       case 2: return launch_one<E, 4, true, true>(b, grid, st);
       case 3: return launch_one<E, 3, true, true>(b, grid, st);
       default: return launch_one<E, 2, true, true>(b, grid, st);
+    }
+  }
+  if constexpr (EPI == VITM_EPI_BIAS) {
+    if (b.img != nullptr) {   // patch embedding: A gathered from the image
+      int rc = launch_one<EPI, 8, false, false, true>(b, grid, st);
+      if (rc != VITM_OK || !b.share) return rc;
+      switch (S) {
+        case 2: return launch_one<EPI, 4, true, false, true>(b, grid, st);
+        case 3: return launch_one<EPI, 3, true, false, true>(b, grid, st);
+        default: return launch_one<EPI, 2, true, false, true>(b, grid, st);
+      }
     }
   }
   int rc = launch_one<EPI, 8, false>(b, grid, st);

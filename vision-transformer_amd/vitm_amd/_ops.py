@@ -202,8 +202,13 @@ def im2col(img: torch.Tensor, A: torch.Tensor, patch, kpad: int, cls_slot: bool)
 
 def patch_embed(img: torch.Tensor, pk: PackedLinear, tokens: torch.Tensor, patch, D: int, cls_slot: bool) -> None:
     B, C, H, W = img.shape
-    if tokens.dtype == torch.bfloat16 and pk.npad == D:
-        # large batch: one pass that writes the patch matrix, then the persistent big-tile GEMM
+    # bf16 images with a power-of-two patch width need no patch matrix: at large batch vitm_patch_embed gathers the
+    # patches inside the big-tile kernel's loader
+    pw = patch[1]
+    gathered = (img.dtype == torch.bfloat16 and pw & (pw - 1) == 0 and 8 <= pw <= 64 and W % 8 == 0
+                and pk.kpad == C * patch[0] * pw and img.data_ptr() % 32 == 0)
+    if tokens.dtype == torch.bfloat16 and pk.npad == D and not gathered:
+        # large batch otherwise: one pass that writes the bf16 patch matrix, then the persistent big-tile GEMM
         npatch = (H // patch[0]) * (W // patch[1])
         rows = B * (npatch + (1 if cls_slot else 0))
         lib = _lib.load()
