@@ -73,7 +73,8 @@ int vitm_prepack_linear(const void* w, int w_dtype, const float* bias, const flo
                         void* wp, int wp_dtype, float* s, float* c, float* g, vitm_stream_t stream);
 
 /*
- * Row statistics of LayerNorm: stats[m] = (mean, 1/sqrt(var + eps)) over x[m, 0:D], x bf16 or f32.
+ * Row statistics of LayerNorm: stats[m] = (mean, 1/sqrt(var + eps)) over x[m, 0:D], x bf16 or f32, D <= 8192
+ * (the limit of vitm_layernorm and vitm_embed_finalize as well: a row is held in registers).
  * First half of nn.LayerNorm (models.py:189,196,310,324); the affine half is folded into the
  * consuming GEMM (VITM_EPI_LN*).
  */

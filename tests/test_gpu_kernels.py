@@ -64,8 +64,6 @@ def test_gemm_big_tile_kernel(ops, M, N, K, epi):
     W, b = _rand(N, K, seed=41, scale=K ** -0.5), _rand(N, seed=42, scale=0.2)
     F = torch.nn.functional
     if epi in ("ln", "ln_gelu"):
-        if K > 2048:
-            pytest.skip("row kernels hold a row in registers: LayerNorm width <= 2048")
         lw, lb = 1.0 + 0.1 * _rand(K, seed=43), 0.1 * _rand(K, seed=44)
         pk = ops.pack_linear(W, b, lw, lb)
         stats = ops.ln_stats(A, M, K, 1e-5)
@@ -300,6 +298,32 @@ def test_patch_embed_large_batch_route(ops, img, p, D, B, dtype):
             ops.gemm(A, pk, tok2, ops.EPI_BIAS, rows)
             got2 = tok2.view(B, Np + int(cls_slot), D)[:, int(cls_slot):]
             assert torch.equal(got, got2), "gathered and patch-matrix routes differ"
+
+
+@pytest.mark.parametrize("D", [2056, 3072, 8192])
+def test_row_kernels_wide_rows(ops, D):
+    """LayerNorm statistics / LayerNorm / embed_finalize on rows wider than 2048 values (16 chunks per lane)."""
+    M = 37
+    F = torch.nn.functional
+    x = _bf(_rand(M, D, seed=70) * 1.7 + 0.3)
+    w, b = 1 + 0.1 * _rand(D, seed=71), 0.1 * _rand(D, seed=72)
+    st = ops.ln_stats(x, M, D, 1e-5)
+    xf = x.float()
+    mean, var = xf.mean(1), xf.var(1, unbiased=False)
+    _close(st[:, 0], mean, rel=1e-5, what="wide ln_stats mean")
+    _close(st[:, 1], torch.rsqrt(var + 1e-5), rel=1e-5, what="wide ln_stats rstd")
+    for dt, rel in ((torch.bfloat16, 6e-3), (torch.float32, 1e-5)):
+        out = torch.empty((M, D), dtype=dt, device=DEV)
+        ops.layernorm(x, out, M, D, w, b, 1e-5)
+        _close(out, F.layer_norm(xf, (D,), w, b, 1e-5), rel=rel, what=f"wide layernorm {dt}")
+    Bn, N = 2, 9
+    tok = _bf(_rand(Bn * N, D, seed=73))
+    cls, pos = _rand(D, seed=74), _rand(N, D, seed=75)
+    y = tok.clone()
+    ops.embed_finalize(y, Bn, N, D, cls, pos, None, None, 0.0, w, b, 1e-5)
+    t = tok.float().view(Bn, N, D).clone()
+    t[:, 0] = cls
+    _close(y.view(Bn, N, D), F.layer_norm(t, (D,), w, b, 1e-5) + pos, rel=6e-3, what="wide embed_finalize")
 
 
 def test_embed_finalize_and_layernorm(ops):

@@ -5,18 +5,20 @@
 //   scale_channels  LayerScale stand-alone
 //   prepack_linear  one-time weight packing (LayerNorm / LayerScale folding, bf16, K padding)
 //   casts           f32 <-> bf16
-// A row is held in registers (up to 4 chunks of 8 values per lane, D <= 2048) so mean and variance are
-// the exact two-pass form over one read of the row.
+// A row is held in registers (NC chunks of 8 values per lane: 4 for D <= 2048, 16 up to 8192) so mean and variance
+// are the exact two-pass form over one read of the row.
 #include "common.h"
 
 namespace {
 
-constexpr int MAXC = 4;               // 8-element chunks per lane
-constexpr int MAXD = 64 * 8 * MAXC;   // 2048
+constexpr int NC_SMALL = 4, NC_WIDE = 16;   // 8-element chunks per lane
+constexpr int MAXD_SMALL = 64 * 8 * NC_SMALL;   // 2048
+constexpr int MAXD = 64 * 8 * NC_WIDE;          // 8192
 constexpr int ROWS_PER_WG = 4;        // 256 threads
 
+template <int NC>
 struct Row {
-  float v[MAXC][8];
+  float v[NC][8];
 };
 
 template <typename T>
@@ -44,10 +46,10 @@ __device__ __forceinline__ void store8(float* p, const float* v) {
   *(float4*)(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
 }
 
-template <typename T>
-__device__ __forceinline__ void load_row(Row& r, const T* x, int D, int lane) {
+template <typename T, int NC>
+__device__ __forceinline__ void load_row(Row<NC>& r, const T* x, int D, int lane) {
 #pragma unroll
-  for (int t = 0; t < MAXC; ++t) {
+  for (int t = 0; t < NC; ++t) {
     const int c = (lane + 64 * t) * 8;
     if (c < D) {
       load8<T>(x + c, r.v[t]);
@@ -59,16 +61,17 @@ __device__ __forceinline__ void load_row(Row& r, const T* x, int D, int lane) {
 }
 
 // two-pass mean / rstd of the row held in r (biased variance, eps inside the sqrt)
-__device__ __forceinline__ void row_stats(const Row& r, int D, int lane, float eps, float& mean, float& rstd) {
+template <int NC>
+__device__ __forceinline__ void row_stats(const Row<NC>& r, int D, int lane, float eps, float& mean, float& rstd) {
   float s = 0.f;
 #pragma unroll
-  for (int t = 0; t < MAXC; ++t)
+  for (int t = 0; t < NC; ++t)
 #pragma unroll
     for (int e = 0; e < 8; ++e) s += r.v[t][e];
   mean = wave_sum(s) / (float)D;
   float q = 0.f;
 #pragma unroll
-  for (int t = 0; t < MAXC; ++t) {
+  for (int t = 0; t < NC; ++t) {
     if ((lane + 64 * t) * 8 < D) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
@@ -81,10 +84,11 @@ __device__ __forceinline__ void row_stats(const Row& r, int D, int lane, float e
   rstd = 1.0f / sqrtf(var + eps);
 }
 
-__device__ __forceinline__ void normalize_row(Row& r, int D, int lane, float mean, float rstd,
+template <int NC>
+__device__ __forceinline__ void normalize_row(Row<NC>& r, int D, int lane, float mean, float rstd,
                                               const float* w, const float* b) {
 #pragma unroll
-  for (int t = 0; t < MAXC; ++t) {
+  for (int t = 0; t < NC; ++t) {
     const int c = (lane + 64 * t) * 8;
     if (c < D) {
       float wv[8], bv[8];
@@ -96,20 +100,20 @@ __device__ __forceinline__ void normalize_row(Row& r, int D, int lane, float mea
   }
 }
 
-template <typename T>
+template <typename T, int NC = NC_SMALL>
 __global__ __launch_bounds__(256) void ln_stats_kernel(const T* __restrict__ x, int64_t ldx, int M, int D,
                                                        float eps, float* __restrict__ stats) {
   const int lane = threadIdx.x & 63;
   const int m = blockIdx.x * ROWS_PER_WG + (threadIdx.x >> 6);
   if (m >= M) return;
-  Row r;
+  Row<NC> r;
   load_row<T>(r, x + (int64_t)m * ldx, D, lane);
   float mean, rstd;
   row_stats(r, D, lane, eps, mean, rstd);
   if (lane == 0) *(float2*)(stats + 2 * (int64_t)m) = make_float2(mean, rstd);
 }
 
-template <typename TI, typename TO>
+template <typename TI, typename TO, int NC = NC_SMALL>
 __global__ __launch_bounds__(256) void layernorm_kernel(const TI* __restrict__ x, int64_t ldx,
                                                         TO* __restrict__ out, int64_t ldo, int M, int D,
                                                         const float* __restrict__ w,
@@ -117,20 +121,20 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const TI* __restrict__ x
   const int lane = threadIdx.x & 63;
   const int m = blockIdx.x * ROWS_PER_WG + (threadIdx.x >> 6);
   if (m >= M) return;
-  Row r;
+  Row<NC> r;
   load_row<TI>(r, x + (int64_t)m * ldx, D, lane);
   float mean, rstd;
   row_stats(r, D, lane, eps, mean, rstd);
   normalize_row(r, D, lane, mean, rstd, w, b);
   TO* o = out + (int64_t)m * ldo;
 #pragma unroll
-  for (int t = 0; t < MAXC; ++t) {
+  for (int t = 0; t < NC; ++t) {
     const int c = (lane + 64 * t) * 8;
     if (c < D) store8(o + c, r.v[t]);
   }
 }
 
-template <typename T>
+template <typename T, int NC = NC_SMALL>
 __global__ __launch_bounds__(256) void embed_finalize_kernel(T* __restrict__ x, int64_t ldx, int rows,
                                                              int ntok, int D, const float* __restrict__ cls,
                                                              const float* __restrict__ pos,
@@ -143,7 +147,7 @@ __global__ __launch_bounds__(256) void embed_finalize_kernel(T* __restrict__ x, 
   if (m >= rows) return;
   const int n = m % ntok;
   T* xr = x + (int64_t)m * ldx;
-  Row r;
+  Row<NC> r;
   float mean, rstd;
   if (n == 0 && cls != nullptr) {
     load_row<float>(r, cls, D, lane);
@@ -159,7 +163,7 @@ __global__ __launch_bounds__(256) void embed_finalize_kernel(T* __restrict__ x, 
     normalize_row(r, D, lane, mean, rstd, np_w, np_b);
   }
 #pragma unroll
-  for (int t = 0; t < MAXC; ++t) {
+  for (int t = 0; t < NC; ++t) {
     const int c = (lane + 64 * t) * 8;
     if (c < D) {
       if (pos != nullptr) {
@@ -416,10 +420,13 @@ extern "C" int vitm_ln_stats(const void* x, int x_dtype, int64_t ldx, int M, int
   VITM_REQUIRE(M > 0 && D > 0 && D % 8 == 0 && D <= MAXD, "vitm_ln_stats: D=%d must be a multiple of 8 and <= %d", D, MAXD);
   VITM_REQUIRE(ldx >= D && ldx % 8 == 0 && al16(x) && ((uintptr_t)stats & 7) == 0, "vitm_ln_stats: ldx/alignment");
   hipStream_t st = (hipStream_t)stream;
+  const bool wide = D > MAXD_SMALL;   // rows beyond 2048 values: 16 chunks per lane
   if (x_dtype == VITM_BF16) {
-    hipLaunchKernelGGL(ln_stats_kernel<bf16_t>, dim3(row_grid(M)), dim3(256), 0, st, (const bf16_t*)x, ldx, M, D, eps, stats);
+    if (wide) hipLaunchKernelGGL((ln_stats_kernel<bf16_t, NC_WIDE>), dim3(row_grid(M)), dim3(256), 0, st, (const bf16_t*)x, ldx, M, D, eps, stats);
+    else hipLaunchKernelGGL(ln_stats_kernel<bf16_t>, dim3(row_grid(M)), dim3(256), 0, st, (const bf16_t*)x, ldx, M, D, eps, stats);
   } else if (x_dtype == VITM_F32) {
-    hipLaunchKernelGGL(ln_stats_kernel<float>, dim3(row_grid(M)), dim3(256), 0, st, (const float*)x, ldx, M, D, eps, stats);
+    if (wide) hipLaunchKernelGGL((ln_stats_kernel<float, NC_WIDE>), dim3(row_grid(M)), dim3(256), 0, st, (const float*)x, ldx, M, D, eps, stats);
+    else hipLaunchKernelGGL(ln_stats_kernel<float>, dim3(row_grid(M)), dim3(256), 0, st, (const float*)x, ldx, M, D, eps, stats);
   } else {
     vitm_set_error("vitm_ln_stats: bad x_dtype %d", x_dtype);
     return VITM_EINVAL;
@@ -438,15 +445,18 @@ extern "C" int vitm_layernorm(const void* x, int x_dtype, int64_t ldx, void* out
                "vitm_layernorm: bad dtype (x %d, out %d)", x_dtype, out_dtype);
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid(row_grid(M)), blk(256);
-  if (x_dtype == VITM_BF16 && out_dtype == VITM_BF16) {
-    hipLaunchKernelGGL((layernorm_kernel<bf16_t, bf16_t>), grid, blk, 0, st, (const bf16_t*)x, ldx, (bf16_t*)out, ldo, M, D, w, b, eps);
-  } else if (x_dtype == VITM_BF16) {
-    hipLaunchKernelGGL((layernorm_kernel<bf16_t, float>), grid, blk, 0, st, (const bf16_t*)x, ldx, (float*)out, ldo, M, D, w, b, eps);
-  } else if (out_dtype == VITM_BF16) {
-    hipLaunchKernelGGL((layernorm_kernel<float, bf16_t>), grid, blk, 0, st, (const float*)x, ldx, (bf16_t*)out, ldo, M, D, w, b, eps);
-  } else {
-    hipLaunchKernelGGL((layernorm_kernel<float, float>), grid, blk, 0, st, (const float*)x, ldx, (float*)out, ldo, M, D, w, b, eps);
-  }
+#define VITM_LN_LAUNCH(TI, TO)                                                                                       \
+  do {                                                                                                               \
+    if (D > MAXD_SMALL)                                                                                              \
+      hipLaunchKernelGGL((layernorm_kernel<TI, TO, NC_WIDE>), grid, blk, 0, st, (const TI*)x, ldx, (TO*)out, ldo, M, D, w, b, eps); \
+    else                                                                                                             \
+      hipLaunchKernelGGL((layernorm_kernel<TI, TO>), grid, blk, 0, st, (const TI*)x, ldx, (TO*)out, ldo, M, D, w, b, eps);          \
+  } while (0)
+  if (x_dtype == VITM_BF16 && out_dtype == VITM_BF16) VITM_LN_LAUNCH(bf16_t, bf16_t);
+  else if (x_dtype == VITM_BF16) VITM_LN_LAUNCH(bf16_t, float);
+  else if (out_dtype == VITM_BF16) VITM_LN_LAUNCH(float, bf16_t);
+  else VITM_LN_LAUNCH(float, float);
+#undef VITM_LN_LAUNCH
   VITM_CHECK_LAUNCH("vitm_layernorm");
   return VITM_OK;
 }
@@ -462,13 +472,17 @@ extern "C" int vitm_embed_finalize(void* x, int x_dtype, int64_t ldx, int B, int
                "vitm_embed_finalize: LayerNorm weight and bias must be given together");
   VITM_REQUIRE(al16(cls) && al16(pos) && al16(en_w) && al16(en_b) && al16(np_w) && al16(np_b), "vitm_embed_finalize: vectors must be 16-byte aligned");
   const int rows = B * ntok;
+#define VITM_EF_LAUNCH(T, NC)                                                                                          \
+  hipLaunchKernelGGL((embed_finalize_kernel<T, NC>), dim3(row_grid(rows)), dim3(256), 0, (hipStream_t)stream, (T*)x, ldx, \
+                     rows, ntok, D, cls, pos, en_w, en_b, en_eps, np_w, np_b, np_eps)
   if (x_dtype == VITM_BF16) {
-    hipLaunchKernelGGL(embed_finalize_kernel<bf16_t>, dim3(row_grid(rows)), dim3(256), 0, (hipStream_t)stream, (bf16_t*)x, ldx,
-                       rows, ntok, D, cls, pos, en_w, en_b, en_eps, np_w, np_b, np_eps);
+    if (D > MAXD_SMALL) VITM_EF_LAUNCH(bf16_t, NC_WIDE);
+    else VITM_EF_LAUNCH(bf16_t, NC_SMALL);
   } else {
-    hipLaunchKernelGGL(embed_finalize_kernel<float>, dim3(row_grid(rows)), dim3(256), 0, (hipStream_t)stream, (float*)x, ldx,
-                       rows, ntok, D, cls, pos, en_w, en_b, en_eps, np_w, np_b, np_eps);
+    if (D > MAXD_SMALL) VITM_EF_LAUNCH(float, NC_WIDE);
+    else VITM_EF_LAUNCH(float, NC_SMALL);
   }
+#undef VITM_EF_LAUNCH
   VITM_CHECK_LAUNCH("vitm_embed_finalize");
   return VITM_OK;
 }
