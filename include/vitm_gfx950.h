@@ -175,7 +175,8 @@ int vitm_embed_finalize(void* x, int x_dtype, int64_t ldx, int B, int ntok, int 
  * Fused multi-head self-attention on a packed qkv activation: qkv is (B*N, 3*D) bf16 laid out as
  * nn.Linear(dim, 3*dim) writes it ([q | k | v], each D = H*hd wide, head-major inside), out is
  * (B*N, D) bf16 token-major:  out = softmax(scale * q k^T) v  per (image, head).
- * head_dim must be 32, 64, 96 or 128.
+ * head_dim is a multiple of 8 up to 128 (64 takes the persistent kernels; dims other than 32 / 96 / 128 run padded
+ * with zeros to the next multiple of 32 inside the kernel, e.g. 80 of ViT-H).
  * Replaces models.py:79-93 (reshape/permute, q*scale, q@k^T, softmax, @v, transpose/reshape).
  */
 int vitm_attention(const void* qkv, int64_t ldqkv, void* out, int64_t ldo, int B, int N, int H,
@@ -184,7 +185,7 @@ int vitm_attention(const void* qkv, int64_t ldqkv, void* out, int64_t ldo, int B
 /*
  * Per-head LayerNorm of q and k, in place on the packed qkv activation (bf16 or fp32): for every row and
  * head, q[h*hd : (h+1)*hd] and k[h*hd : (h+1)*hd] are normalised over head_dim with (q_w, q_b, q_eps) /
- * (k_w, k_b, k_eps); v is untouched.  Run it between the qkv GEMM and vitm_attention.
+ * (k_w, k_b, k_eps); v is untouched (head_dim 32, 64, 96 or 128).  Run it between the qkv GEMM and vitm_attention.
  * Replaces q_norm / k_norm of Attention(qk_norm=True) (models.py:54-55,82).
  */
 int vitm_qk_norm(void* qkv, int dtype, int64_t ldqkv, int M, int H, int head_dim, const float* q_w,
@@ -193,7 +194,7 @@ int vitm_qk_norm(void* qkv, int dtype, int64_t ldqkv, int M, int H, int head_dim
 
 /*
  * Same attention with fp32 qkv and out and fp32 arithmetic throughout (leading dimensions multiples
- * of 4).  Replaces models.py:79-93 for fp32 tensors.
+ * of 4; head_dim a multiple of 4 up to 128).  Replaces models.py:79-93 for fp32 tensors.
  */
 int vitm_attention_f32(const float* qkv, int64_t ldqkv, float* out, int64_t ldo, int B, int N, int H,
                        int head_dim, float scale, vitm_stream_t stream);

@@ -87,7 +87,9 @@ def _attn_ref(qkv, B, N, H, hd):
 
 
 @pytest.mark.parametrize("B,N,H,hd", [(2, 197, 3, 64), (1, 65, 2, 64), (1, 577, 2, 64), (2, 1, 2, 64), (1, 65, 2, 96),
-                                      (1, 197, 2, 32), (1, 100, 1, 128), (1, 300, 1, 64)])
+                                      (1, 197, 2, 32), (1, 100, 1, 128), (1, 300, 1, 64),
+                                      # head dims that run padded to the next multiple of 32
+                                      (2, 257, 3, 80), (1, 65, 2, 48), (1, 50, 3, 20), (1, 197, 2, 4), (1, 70, 1, 120)])
 def test_attention_f32(ops, B, N, H, hd):
     D = H * hd
     qkv = _rand(B * N, 3 * D, seed=20) * 1.5

@@ -215,7 +215,10 @@ def _attn_ref(qkv, B, N, H, hd):
 
 @pytest.mark.parametrize("B,N,H,hd", [(2, 197, 3, 64), (1, 65, 2, 64), (1, 577, 2, 64), (3, 32, 1, 64),
                                       (2, 1, 2, 64), (1, 65, 2, 96), (1, 197, 2, 32), (1, 100, 1, 128),
-                                      (1, 300, 1, 64)])
+                                      (1, 300, 1, 64),
+                                      # head dims the kernels pad to the next multiple of 32 (80: ViT-H/14)
+                                      (2, 257, 3, 80), (1, 65, 2, 48), (1, 197, 2, 8), (1, 50, 3, 40), (1, 130, 2, 104),
+                                      (1, 70, 1, 120)])
 def test_attention(ops, B, N, H, hd):
     D = H * hd
     qkv = _bf(_rand(B * N, 3 * D, seed=20) * 1.5)

@@ -237,6 +237,33 @@ def test_layernorm_without_affine():
         assert rel_err(blk(x).cpu(), ref.cpu()) < 1e-4
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_head_dim_80_model_against_oracle(dtype):
+    """A head dimension outside {32, 64, 96, 128} (80, as in ViT-H/14: 1280 / 16) runs padded inside the attention
+    kernels; the whole forward is checked against the oracle (no reference fixture: the oracle is the pinned one)."""
+    from oracle import vit_oracle as O
+    from vitm_amd.models import VisionTransformer, VITC
+    cfg = dict(image_size=32, patch_size=4, embed_dim=160, num_heads=2, depth=2, mlp_ratio=4.0, num_classes=10,
+               embed_norm=False, norm_pre=True, final_norm=True, patch_bias=False)
+    LN = nn.LayerNorm
+    vt = VisionTransformer(32, patch_size=4, num_classes=10, num_heads=2, mlp_ratio=4.0, depth=2, embed_dim=160,
+                           norm_layer=LN, embed_norm_layer=None, final_norm_layer=LN)
+    model = VITC(vt).eval()
+    sd = {k: torch.from_numpy(v) for k, v in W.make_state_dict(cfg, 21).items()}
+    model.load_state_dict(sd, strict=True)
+    model = model.to(device="cuda", dtype=dtype)
+    x = torch.from_numpy(W.make_input(cfg, 3, 22))
+    ref_logits, ref_emb = O.vitc_forward(x, sd, W.oracle_cfg(cfg), torch.float32, return_embeddings=True)
+    with torch.no_grad():
+        logits = model(x.cuda().to(dtype)).float().cpu()
+        emb = model.vit_model(x.cuda().to(dtype)).float().cpu()
+    if dtype == torch.float32:
+        assert rel_err(logits, ref_logits) <= 1e-4 and rel_err(emb, ref_emb) <= 1e-4
+    else:
+        assert cos_rows(emb, ref_emb) >= 0.999
+        assert (logits - ref_logits).abs().max().item() <= logit_tol(ref_logits)
+
+
 def test_batch_independence_and_determinism():
     """Images are independent: a batch equals its halves run separately (the multi-GPU sharding invariant),
     and two runs are bit-identical."""

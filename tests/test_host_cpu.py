@@ -48,10 +48,10 @@ def test_argument_errors_are_reported_before_any_launch():
     p = ctypes.c_void_p(addr)
     rc = lib.vitm_gemm(p, 100, p, 100, p, 8, 0, 8, 8, 100, 0, None, None, p, None, None, 0, 0, None)
     assert rc == -1 and b"multiple of 64" in lib.vitm_last_error()
-    rc = lib.vitm_attention(p, 3 * 48, p, 48, 1, 4, 1, 48, ctypes.c_float(0.1), None)
+    rc = lib.vitm_attention(p, 3 * 136, p, 136, 1, 4, 1, 136, ctypes.c_float(0.1), None)
     assert rc == -3 and b"head_dim" in lib.vitm_last_error()
-    rc = lib.vitm_ln_stats(p, 0, 4096, 4, 4096, ctypes.c_float(1e-5), p, None)
-    assert rc == -1 and b"2048" in lib.vitm_last_error()
+    rc = lib.vitm_ln_stats(p, 0, 16384, 4, 16384, ctypes.c_float(1e-5), p, None)
+    assert rc == -1 and b"8192" in lib.vitm_last_error()
     rc = lib.vitm_patch_embed(p, 1, 1, 3, 32, 32, 64, 64, p, 64, 64, p, p, 8, 8, 1, None)
     assert rc == -1
 

@@ -30,11 +30,14 @@ __device__ __forceinline__ u16x4_t tr_read(const char* lds_addr) {
   return __builtin_bit_cast(u16x4_t, v);
 }
 
-template <int HD>
+// HD is the head dimension the arithmetic runs at (a multiple of 32); hd <= HD is the real one (a multiple of 8).
+// EXACT (hd == HD) compiles the padding away; otherwise columns hd .. HD-1 of Q, K and V are zeros in registers / LDS
+// (they add nothing to the scores) and the matching output columns are not stored.
+template <int HD, bool EXACT>
 __global__ __launch_bounds__(WAVES * 64) void attn_kernel(const bf16_t* __restrict__ qkv, int64_t ldq,
                                                           bf16_t* __restrict__ out, int64_t ldo, int N,
                                                           int H, float sl2e, int kchunk, int nqg,
-                                                          float* __restrict__ lse) {
+                                                          float* __restrict__ lse, int hd) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int RS = HD * 2 + 16;     // LDS row stride in bytes
   constexpr int CPR = HD / 8;         // 16-byte chunks per row
@@ -48,11 +51,12 @@ __global__ __launch_bounds__(WAVES * 64) void attn_kernel(const bf16_t* __restri
   const int r = lane & 31, hh = lane >> 5;
   const int bh = blockIdx.x / nqg, qg = blockIdx.x - bh * nqg;
   const int b = bh / H, h = bh - b * H;
-  const int D = H * HD;
+  if (EXACT) hd = HD;
+  const int D = H * hd;
   const int q0 = (qg * WAVES + wave) * QB;
   const bool active = q0 < N;  // wave-uniform
 
-  const bf16_t* base = qkv + (int64_t)b * N * ldq + h * HD;
+  const bf16_t* base = qkv + (int64_t)b * N * ldq + h * hd;
 
   // Q fragments (B operand of S^T = K.Q^T): lane (r, hh) holds Q[q0 + r][16 s + 8 hh + 0..7]
   bf16x8_t qf[KS];
@@ -61,7 +65,10 @@ __global__ __launch_bounds__(WAVES * 64) void attn_kernel(const bf16_t* __restri
     qrow = qrow < N ? qrow : N - 1;  // rows past N are computed on a copy of the last row and never stored
     const bf16_t* qp = base + (int64_t)qrow * ldq + 8 * hh;
 #pragma unroll
-    for (int s = 0; s < KS; ++s) qf[s] = *(const bf16x8_t*)(qp + 16 * s);
+    for (int s = 0; s < KS; ++s) {
+      if (EXACT || 16 * s + 8 * hh < hd) qf[s] = *(const bf16x8_t*)(qp + 16 * s);
+      else qf[s] = __builtin_bit_cast(bf16x8_t, (u16x8_t){0, 0, 0, 0, 0, 0, 0, 0});
+    }
   }
 
   f32x16_t o[DB];
@@ -82,7 +89,7 @@ __global__ __launch_bounds__(WAVES * 64) void attn_kernel(const bf16_t* __restri
     for (int idx = tid; idx < rows_pad * CPR; idx += WAVES * 64) {
       const int row = idx / CPR, ch = idx - row * CPR;
       uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
-      if (row < rows) {
+      if (row < rows && (EXACT || ch * 8 < hd)) {
         const bf16_t* src = base + (int64_t)(c0 + row) * ldq + ch * 8;
         kv = *(const uint4*)(src + D);
         vv = *(const uint4*)(src + 2 * D);
@@ -166,7 +173,7 @@ __global__ __launch_bounds__(WAVES * 64) void attn_kernel(const bf16_t* __restri
   // log2-domain log-sum-exp of the scaled scores (training): p = exp2(s * scale * log2e - lse)
   if (lse != nullptr && hh == 0 && q0 + r < N) lse[((int64_t)b * H + h) * N + q0 + r] = m_run * sl2e + __log2f(l);
   if (q0 + r < N) {
-    bf16_t* op = out + ((int64_t)b * N + q0 + r) * ldo + h * HD;
+    bf16_t* op = out + ((int64_t)b * N + q0 + r) * ldo + h * hd;
 #pragma unroll
     for (int d = 0; d < DB; ++d)
 #pragma unroll
@@ -174,24 +181,24 @@ __global__ __launch_bounds__(WAVES * 64) void attn_kernel(const bf16_t* __restri
         uint2 w;
         w.x = pack_bf2(o[d][4 * g + 0] * inv, o[d][4 * g + 1] * inv);
         w.y = pack_bf2(o[d][4 * g + 2] * inv, o[d][4 * g + 3] * inv);
-        *(uint2*)(op + 32 * d + 8 * g + 4 * hh) = w;
+        if (EXACT || 32 * d + 8 * g + 4 * hh < hd) *(uint2*)(op + 32 * d + 8 * g + 4 * hh) = w;
       }
   }
 }
 
-template <int HD>
+template <int HD, bool EXACT>
 int launch_attn(const void* qkv, int64_t ldq, void* out, int64_t ldo, int B, int N, int H, float scale,
-                float* lse, hipStream_t st) {
+                float* lse, int hd, hipStream_t st) {
   const int npad = (N + KT - 1) / KT * KT;
   const int kchunk = npad < KCHUNK_MAX ? npad : KCHUNK_MAX;
   const int smem = 2 * kchunk * (HD * 2 + 16);
-  auto kfn = attn_kernel<HD>;
+  auto kfn = attn_kernel<HD, EXACT>;
   VITM_LDS_OPTIN(kfn, 2 * KCHUNK_MAX * (HD * 2 + 16), "vitm_attention");   // once, for the largest chunk
   const int nqb = (N + QB - 1) / QB;
   const int nqg = (nqb + WAVES - 1) / WAVES;
   dim3 grid((unsigned)((int64_t)nqg * B * H));
   hipLaunchKernelGGL(kfn, grid, dim3(WAVES * 64), smem, st, (const bf16_t*)qkv, ldq, (bf16_t*)out, ldo, N, H,
-                     scale * 1.4426950408889634f, kchunk, nqg, lse);
+                     scale * 1.4426950408889634f, kchunk, nqg, lse, hd);
   VITM_CHECK_LAUNCH("vitm_attention");
   return VITM_OK;
 }
@@ -906,15 +913,21 @@ static int attention_impl(const void* qkv, int64_t ldqkv, void* out, int64_t ldo
     if (N <= 32 * short_seq::MAX_TILES) return short_seq::launch(qkv, ldqkv, out, ldo, B, N, H, scale, lse, st);
     return short_seq::launch_long(qkv, ldqkv, out, ldo, B, N, H, scale, lse, st);
   }
-  switch (head_dim) {
-    case 32: return launch_attn<32>(qkv, ldqkv, out, ldo, B, N, H, scale, lse, st);
-    case 64: return launch_attn<64>(qkv, ldqkv, out, ldo, B, N, H, scale, lse, st);
-    case 96: return launch_attn<96>(qkv, ldqkv, out, ldo, B, N, H, scale, lse, st);
-    case 128: return launch_attn<128>(qkv, ldqkv, out, ldo, B, N, H, scale, lse, st);
-    default: break;
+  if (head_dim <= 0 || head_dim % 8 != 0 || head_dim > 128) {
+    vitm_set_error("vitm_attention: head_dim=%d unsupported (a multiple of 8, at most 128)", head_dim);
+    return VITM_EUNSUPPORTED;
   }
-  vitm_set_error("vitm_attention: head_dim=%d unsupported (32, 64, 96, 128)", head_dim);
-  return VITM_EUNSUPPORTED;
+  const int hd = head_dim;
+  switch ((hd + 31) / 32) {   // the arithmetic runs at the next multiple of 32
+    case 1: return hd == 32 ? launch_attn<32, true>(qkv, ldqkv, out, ldo, B, N, H, scale, lse, hd, st)
+                            : launch_attn<32, false>(qkv, ldqkv, out, ldo, B, N, H, scale, lse, hd, st);
+    case 2: return hd == 64 ? launch_attn<64, true>(qkv, ldqkv, out, ldo, B, N, H, scale, lse, hd, st)
+                            : launch_attn<64, false>(qkv, ldqkv, out, ldo, B, N, H, scale, lse, hd, st);
+    case 3: return hd == 96 ? launch_attn<96, true>(qkv, ldqkv, out, ldo, B, N, H, scale, lse, hd, st)
+                            : launch_attn<96, false>(qkv, ldqkv, out, ldo, B, N, H, scale, lse, hd, st);
+    default: return hd == 128 ? launch_attn<128, true>(qkv, ldqkv, out, ldo, B, N, H, scale, lse, hd, st)
+                              : launch_attn<128, false>(qkv, ldqkv, out, ldo, B, N, H, scale, lse, hd, st);
+  }
 }
 
 extern "C" int vitm_attention(const void* qkv, int64_t ldqkv, void* out, int64_t ldo, int B, int N, int H,

@@ -14,10 +14,13 @@ namespace {
 constexpr int QPB = 64;      // queries per workgroup
 constexpr int SUB = 8;       // keys per online-softmax step
 
-template <int HD>
+// HD is the head dimension the arithmetic runs at (a multiple of 16); hd <= HD is the real one (a multiple of 4).
+// EXACT (hd == HD) compiles the padding away; otherwise columns hd .. HD-1 of q, K and V are zeros and the matching
+// output columns are not stored.
+template <int HD, bool EXACT>
 __global__ __launch_bounds__(256) void attn_f32_kernel(const float* __restrict__ qkv, int64_t ldq,
                                                        float* __restrict__ out, int64_t ldo, int N, int H,
-                                                       float sl2e, int kchunk, int nqb, float* __restrict__ lse) {
+                                                       float sl2e, int kchunk, int nqb, float* __restrict__ lse, int hd) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int DP = HD / 4;      // head-dim slice per lane
   constexpr int V4 = DP / 4;      // float4 per slice
@@ -29,8 +32,9 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(const float* __restrict__
   const int ql = tid >> 2, part = tid & 3;
   const int bh = blockIdx.x / nqb, qb = blockIdx.x - bh * nqb;
   const int b = bh / H, h = bh - b * H;
-  const int D = H * HD;
-  const float* base = qkv + (int64_t)b * N * ldq + h * HD;
+  if (EXACT) hd = HD;
+  const int D = H * hd;
+  const float* base = qkv + (int64_t)b * N * ldq + h * hd;
 
   int qrow = qb * QPB + ql;
   const bool store = qrow < N;
@@ -41,7 +45,7 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(const float* __restrict__
     const float* qp = base + (int64_t)qrow * ldq + part * DP;
 #pragma unroll
     for (int v = 0; v < V4; ++v) {
-      const float4 t = *(const float4*)(qp + 4 * v);
+      const float4 t = (EXACT || part * DP + 4 * v < hd) ? *(const float4*)(qp + 4 * v) : make_float4(0.f, 0.f, 0.f, 0.f);
       q[4 * v + 0] = t.x * sl2e; q[4 * v + 1] = t.y * sl2e; q[4 * v + 2] = t.z * sl2e; q[4 * v + 3] = t.w * sl2e;
     }
   }
@@ -56,7 +60,7 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(const float* __restrict__
     for (int idx = tid; idx < rows_pad * CPR; idx += 256) {
       const int row = idx / CPR, ch = idx - row * CPR;
       float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
-      if (row < rows) {
+      if (row < rows && (EXACT || ch * 4 < hd)) {
         const float* src = base + (int64_t)(c0 + row) * ldq + ch * 4;
         kv = *(const float4*)(src + D);
         vv = *(const float4*)(src + 2 * D);
@@ -116,27 +120,27 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(const float* __restrict__
 
   if (store) {
     const float inv = 1.0f / l_run;
-    float* op = out + ((int64_t)b * N + qrow) * ldo + h * HD + part * DP;
+    float* op = out + ((int64_t)b * N + qrow) * ldo + h * hd + part * DP;
 #pragma unroll
     for (int v = 0; v < V4; ++v)
-      *(float4*)(op + 4 * v) = make_float4(o[4 * v] * inv, o[4 * v + 1] * inv, o[4 * v + 2] * inv, o[4 * v + 3] * inv);
+      if (EXACT || part * DP + 4 * v < hd) *(float4*)(op + 4 * v) = make_float4(o[4 * v] * inv, o[4 * v + 1] * inv, o[4 * v + 2] * inv, o[4 * v + 3] * inv);
     // log2-domain log-sum-exp of the scaled scores, kept for the backward pass: p = exp2(s * scale * log2e - lse)
     if (lse != nullptr && part == 0) lse[((int64_t)b * H + h) * N + qrow] = m_run + __log2f(l_run);
   }
 }
 
-template <int HD>
+template <int HD, bool EXACT>
 int launch_attn_f32(const float* qkv, int64_t ldq, float* out, int64_t ldo, int B, int N, int H, float scale,
-                    float* lse, hipStream_t st) {
+                    float* lse, int hd, hipStream_t st) {
   int kchunk = (8192 / HD) / SUB * SUB;          // 64 KiB of LDS for K and V together
   const int npad = (N + SUB - 1) / SUB * SUB;
   if (npad < kchunk) kchunk = npad;
   const int smem = 2 * kchunk * HD * 4;
-  auto kfn = attn_f32_kernel<HD>;
+  auto kfn = attn_f32_kernel<HD, EXACT>;
   VITM_LDS_OPTIN(kfn, 2 * ((8192 / HD) / SUB * SUB) * HD * 4, "vitm_attention_f32");   // once, for the largest chunk
   const int nqb = (N + QPB - 1) / QPB;
   hipLaunchKernelGGL(kfn, dim3((unsigned)((int64_t)nqb * B * H)), dim3(256), smem, st, qkv, ldq, out, ldo, N, H,
-                     scale * 1.4426950408889634f, kchunk, nqb, lse);
+                     scale * 1.4426950408889634f, kchunk, nqb, lse, hd);
   VITM_CHECK_LAUNCH("vitm_attention_f32");
   return VITM_OK;
 }
@@ -154,15 +158,21 @@ static int attention_f32_impl(const float* qkv, int64_t ldqkv, float* out, int64
   VITM_REQUIRE(((uintptr_t)qkv & 15) == 0 && ((uintptr_t)out & 15) == 0, "vitm_attention_f32: pointers must be 16-byte aligned");
   VITM_REQUIRE(scale > 0.f, "vitm_attention_f32: scale must be positive");
   hipStream_t st = (hipStream_t)stream;
-  switch (head_dim) {
-    case 32: return launch_attn_f32<32>(qkv, ldqkv, out, ldo, B, N, H, scale, lse, st);
-    case 64: return launch_attn_f32<64>(qkv, ldqkv, out, ldo, B, N, H, scale, lse, st);
-    case 96: return launch_attn_f32<96>(qkv, ldqkv, out, ldo, B, N, H, scale, lse, st);
-    case 128: return launch_attn_f32<128>(qkv, ldqkv, out, ldo, B, N, H, scale, lse, st);
-    default: break;
+  if (head_dim <= 0 || head_dim % 4 != 0 || head_dim > 128) {
+    vitm_set_error("vitm_attention_f32: head_dim=%d unsupported (a multiple of 4, at most 128)", head_dim);
+    return VITM_EUNSUPPORTED;
   }
-  vitm_set_error("vitm_attention_f32: head_dim=%d unsupported (32, 64, 96, 128)", head_dim);
-  return VITM_EUNSUPPORTED;
+  const int hd = head_dim;
+  switch ((hd + 31) / 32) {   // the arithmetic runs at the next multiple of 32
+    case 1: return hd == 32 ? launch_attn_f32<32, true>(qkv, ldqkv, out, ldo, B, N, H, scale, lse, hd, st)
+                            : launch_attn_f32<32, false>(qkv, ldqkv, out, ldo, B, N, H, scale, lse, hd, st);
+    case 2: return hd == 64 ? launch_attn_f32<64, true>(qkv, ldqkv, out, ldo, B, N, H, scale, lse, hd, st)
+                            : launch_attn_f32<64, false>(qkv, ldqkv, out, ldo, B, N, H, scale, lse, hd, st);
+    case 3: return hd == 96 ? launch_attn_f32<96, true>(qkv, ldqkv, out, ldo, B, N, H, scale, lse, hd, st)
+                            : launch_attn_f32<96, false>(qkv, ldqkv, out, ldo, B, N, H, scale, lse, hd, st);
+    default: return hd == 128 ? launch_attn_f32<128, true>(qkv, ldqkv, out, ldo, B, N, H, scale, lse, hd, st)
+                              : launch_attn_f32<128, false>(qkv, ldqkv, out, ldo, B, N, H, scale, lse, hd, st);
+  }
 }
 
 extern "C" int vitm_attention_f32(const float* qkv, int64_t ldqkv, float* out, int64_t ldo, int B, int N, int H,

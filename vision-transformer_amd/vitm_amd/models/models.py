@@ -32,7 +32,7 @@ from .. import _ops
 from ..utils.helper import to_2tuple
 from .patch_embeddings import PatchEmbed, layernorm_params
 
-_SUPPORTED_HEAD_DIMS = (32, 64, 96, 128)
+_SUPPORTED_HEAD_DIMS = (32, 64, 96, 128)   # per-head LayerNorm (qk_norm) and the attention backward; the forward pads others
 # bf16, big-tile shapes: LayerNorm row moments ride from the proj / fc2 epilogue to the qkv / fc1 epilogue
 # (vitm_gemm_stats); False recomputes them with vitm_ln_stats in front of every LayerNorm-folded GEMM.
 CARRY_LN_STATS = True
@@ -100,9 +100,13 @@ class Attention(nn.Module):
 
     # ---- HIP path --------------------------------------------------------------------------------
     def _check(self):
-        if self.head_dim * self.num_heads != self.dim or self.head_dim not in _SUPPORTED_HEAD_DIMS:
+        hd = self.head_dim
+        if hd * self.num_heads != self.dim or hd % 8 != 0 or hd > 128:
             raise NotImplementedError(f"head_dim {self.dim}/{self.num_heads} unsupported; the fused attention kernel "
-                                      f"handles head_dim in {_SUPPORTED_HEAD_DIMS}")
+                                      f"handles head dims that are multiples of 8 up to 128")
+        if not isinstance(self.q_norm, nn.Identity) and hd not in _SUPPORTED_HEAD_DIMS:
+            raise NotImplementedError(f"qk_norm with head_dim {hd} unsupported; the per-head LayerNorm kernel handles "
+                                      f"head_dim in {_SUPPORTED_HEAD_DIMS}")
 
     def _qkv_pack(self, dtype, ln=None) -> _ops.PackedLinear:
         return _pack(self, "qkv", dtype, self.qkv.weight, self.qkv.bias, ln=ln)

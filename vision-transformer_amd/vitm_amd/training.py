@@ -72,6 +72,8 @@ def supported(model) -> Optional[str]:
     if vt.embed_dim % 8 != 0:
         return "embed_dim must be a multiple of 8 for the activation-keeping forward"
     for blk in vt.blocks:
+        if blk.attn.head_dim not in (32, 64, 96, 128):
+            return f"the attention backward handles head_dim 32, 64, 96 and 128, not {blk.attn.head_dim}"
         if type(blk) is ParallelBlock:
             continue
         if type(blk) is not Block:
