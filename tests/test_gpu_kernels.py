@@ -375,5 +375,5 @@ def test_bad_arguments_report_errors(ops):
     with pytest.raises((VitmError, AssertionError)):
         ops.gemm(A[:, :32], pk, torch.empty((8, 8), dtype=torch.bfloat16, device=DEV), ops.EPI_BIAS, 8)
     with pytest.raises(VitmError):
-        ops.attention(torch.zeros((4, 3 * 48), dtype=torch.bfloat16, device=DEV),
-                      torch.zeros((4, 48), dtype=torch.bfloat16, device=DEV), 1, 4, 1, 48, 0.1)
+        ops.attention(torch.zeros((4, 3 * 136), dtype=torch.bfloat16, device=DEV),
+                      torch.zeros((4, 136), dtype=torch.bfloat16, device=DEV), 1, 4, 1, 136, 0.1)
