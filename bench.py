@@ -383,7 +383,7 @@ def main():
             "roofline": {"bound": "mfma", "achieved": round(fc1_tflops, 1), "peak": PEAK_BF16_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(fc1_tflops / PEAK_BF16_TFLOPS, 4),
                          "traffic": measured_traffic(args.config, args.batch),
-                         "kernel": "gemm_pp_kernel<EPI_LN_GELU> (fc1: LayerNorm-folded 256x256 ping-pong GEMM + GELU; main launch + leftover-tile slice launch)",
+                         "kernel": "gemm_pp_shared_kernel<EPI_LN_GELU> (fc1: LayerNorm-folded 256x256 ping-pong GEMM + GELU; whole tiles and the leftover-tile slices in one launch)",
                          "flops_per_launch": 2.0 * M * N * K, "avg_launch_ms": round(fc1_ms, 4),
                          "launches_timed": n_launch},
             "whole_forward": {"tflops_per_gpu": round(model_tflops, 1),

@@ -86,7 +86,10 @@ def main(rnd: str) -> None:
                 w.writerow([k, "=MFMA_BUSY_FRACTION (busy cycles / (1024 SIMDs x kernel cycles))",
                             f"{c['SQ_VALU_MFMA_BUSY_CYCLES'][0] / (SIMDS * cycles):.4f}", ""])
     # ---- fc1 traffic for bench.py
-    fc1 = [k for k in per if k.startswith("gemm_pp_kernel<3, 8, false")]
+    # fc1 = the LN + GELU epilogue (3): one launch that also runs the leftover-tile slices (gemm_pp_shared_kernel), or,
+    # in trees before that, a whole-tile launch (gemm_pp_kernel<3, 8, false..>) plus a slice launch (<3, 2, true..>)
+    fc1 = ([k for k in per if k.startswith("gemm_pp_shared_kernel<3,")]
+           or [k for k in per if k.startswith("gemm_pp_kernel<3, 8, false")])
     if fc1 and "FETCH_SIZE" in per[fc1[0]] and "WRITE_SIZE" in per[fc1[0]]:
         c = per[fc1[0]]
         slice_k = [k for k in per if k.startswith("gemm_pp_kernel<3, 2, true")]
@@ -97,8 +100,8 @@ def main(rnd: str) -> None:
         json.dump({"config": "vit_b16", "batch_per_gpu": 256, "kernel": fc1[0],
                    "fetch_size_kib": c["FETCH_SIZE"][0], "write_size_kib": c["WRITE_SIZE"][0],
                    "slice_launch_bytes": extra, "hbm_bytes_per_launch": hbm + extra,
-                   "note": "FETCH_SIZE x2 (gfx950 counts 64-byte requests as 32 bytes); separate --pmc passes; main "
-                           "launch plus the leftover-tile slice launch of one fc1 GEMM"},
+                   "note": "FETCH_SIZE x2 (gfx950 counts 64-byte requests as 32 bytes); separate --pmc passes; one "
+                           "fc1 GEMM, leftover-tile slices included"},
                   open(os.path.join(out, f"{rnd}_fc1_traffic.json"), "w"), indent=1)
     # ---- HBM bytes of a whole forward: sum over kernels of (bytes per dispatch) x (dispatches per forward); the
     # dispatch counts come from the kernel-trace pass, one embed_finalize launch = one forward

@@ -33,8 +33,8 @@
 // 16-byte bank slots.
 //
 // Tile-count quantisation.  With T tiles on G workgroups the last round is only partly filled (591 tiles on 256
-// CUs: 2.31 rounds cost 3).  When that wastes enough, the launcher runs the whole rounds with this kernel and the
-// leftover tiles with its SLICE instantiation: each XCD group shares its leftover tiles, S = min(4, workgroups /
+// CUs: 2.31 rounds cost 3).  When that wastes enough, a workgroup runs its whole tiles and then, in the same launch,
+// a SLICE pass over the leftover tiles: each XCD group shares its leftover tiles, S = min(4, workgroups /
 // leftover tiles) workgroups per tile, each taking NBLK = ceil(8 / S) of the tile's 16-row blocks (block range
 // [i0, i0 + NBLK) of BOTH wave groups, i.e. rows 16 i .. and 128 + 16 i ..).  A slice moves only its own A rows
 // and has NBLK x 4 MFMAs per segment; every output element is still produced by exactly one wave with the same
@@ -154,7 +154,7 @@ __host__ __device__ inline Deal deal_tiles(int T, int nwg, int xg, bool share, i
   return d;
 }
 
-// SLICE = false: NBLK = 8, whole tiles (p.share: the leftover tiles are left to the SLICE launch).
+// SLICE = false: NBLK = 8, whole tiles (p.share: the leftover tiles are left to the SLICE pass).
 // SLICE = true:  one slice of NBLK 16-row blocks (of both wave groups) of one leftover tile per workgroup.
 // STATS (RESIDUAL epilogue only): also write the per-row raw moments of this tile's output values (p.stats_out).
 // IM2COL (patch embedding): the A operand is never materialised -- row m of A is patch (or class-token slot) m of the
@@ -162,8 +162,7 @@ __host__ __device__ inline Deal deal_tiles(int T, int nwg, int xg, bool share, i
 // (patch width a power of two >= 8, so a chunk never straddles patch rows and the pixel column of a lane is the same in
 // every K-tile); from one K-tile to the next a lane moves down 64 / pw image rows, wrapping into the next channel.
 template <int EPI, int NBLK, bool SLICE, bool STATS = false, bool IM2COL = false>
-__global__ __launch_bounds__(NT, 2) void gemm_pp_kernel(const GemmArgs p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+__device__ __forceinline__ void tile_loop(const GemmArgs& p, char* smem) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -660,13 +659,48 @@ __global__ __launch_bounds__(NT, 2) void gemm_pp_kernel(const GemmArgs p) {
   }
 }
 
-template <int EPI, int NBLK, bool SLICE, bool STATS = false, bool IM2COL = false>
+// Whole tiles only (every tile of the launch when nothing is shared).
+template <int EPI, bool STATS = false, bool IM2COL = false>
+__global__ __launch_bounds__(NT, 2) void gemm_pp_kernel(const GemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  tile_loop<EPI, 8, false, STATS, IM2COL>(p, smem);
+}
+
+// Whole rounds, then this workgroup's slice of a shared leftover tile (NBLK_S 16-row blocks of both wave groups), in
+// one launch: a workgroup moves on to its slice as soon as its own whole tiles are done, instead of waiting at a kernel
+// boundary for the slowest workgroup of the chip.
+template <int EPI, int NBLK_S, bool STATS = false, bool IM2COL = false>
+__global__ __launch_bounds__(NT, 2) void gemm_pp_shared_kernel(const GemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  tile_loop<EPI, 8, false, STATS, IM2COL>(p, smem);
+  wait_lds();       // the LDS reads of the last whole tile (moments combine) are over before the ring is refilled
+  seg_barrier();
+  tile_loop<EPI, NBLK_S, true, STATS, IM2COL>(p, smem);
+}
+
+template <int EPI, int NBLK_S, bool STATS = false, bool IM2COL = false>   // NBLK_S = 8: nothing shared
 int launch_one(const GemmArgs& b, int grid, hipStream_t st) {
-  auto kfn = gemm_pp_kernel<EPI, NBLK, SLICE, STATS, IM2COL>;
-  VITM_LDS_OPTIN(kfn, SMEM, "vitm_gemm");
-  hipLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3(NT), SMEM, st, b);
+  if constexpr (NBLK_S == 8) {
+    auto kfn = gemm_pp_kernel<EPI, STATS, IM2COL>;
+    VITM_LDS_OPTIN(kfn, SMEM, "vitm_gemm");
+    hipLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3(NT), SMEM, st, b);
+  } else {
+    auto kfn = gemm_pp_shared_kernel<EPI, NBLK_S, STATS, IM2COL>;
+    VITM_LDS_OPTIN(kfn, SMEM, "vitm_gemm");
+    hipLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3(NT), SMEM, st, b);
+  }
   VITM_CHECK_LAUNCH("vitm_gemm (256x256 tile)");
   return VITM_OK;
+}
+
+// S workgroups per leftover tile -> blocks per slice
+template <int EPI, bool STATS, bool IM2COL>
+int launch_shared(const GemmArgs& b, int grid, int S, hipStream_t st) {
+  switch (S) {
+    case 2: return launch_one<EPI, 4, STATS, IM2COL>(b, grid, st);
+    case 3: return launch_one<EPI, 3, STATS, IM2COL>(b, grid, st);
+    default: return launch_one<EPI, 2, STATS, IM2COL>(b, grid, st);
+  }
 }
 
 template <int EPI>
@@ -692,7 +726,7 @@ int launch(const GemmArgs& a, hipStream_t st) {
 #endif
   b.ncu = grid;
   // Share the leftover tiles of a partly filled last round when that round would be less than ~70 % full and
-  // there is at least one whole round to amortise the second launch over.
+  // there is at least one whole round to amortise the slice pass over.
   const int rounds = (int)((tiles + grid - 1) / grid);
   const int64_t left = tiles - (int64_t)(rounds - 1) * grid;
   b.share = (rounds >= 2 && left * 10 < (int64_t)grid * 7 && (grid & 7) == 0) ? 1 : 0;
@@ -709,32 +743,13 @@ int launch(const GemmArgs& a, hipStream_t st) {
   b.S = S;
   if (EPI == VITM_EPI_RESIDUAL && b.stats_out != nullptr) {
     constexpr int E = VITM_EPI_RESIDUAL;   // the only epilogue whose output feeds a LayerNorm
-    int rc = launch_one<E, 8, false, true>(b, grid, st);
-    if (rc != VITM_OK || !b.share) return rc;
-    switch (S) {
-      case 2: return launch_one<E, 4, true, true>(b, grid, st);
-      case 3: return launch_one<E, 3, true, true>(b, grid, st);
-      default: return launch_one<E, 2, true, true>(b, grid, st);
-    }
+    return b.share ? launch_shared<E, true, false>(b, grid, S, st) : launch_one<E, 8, true>(b, grid, st);
   }
   if constexpr (EPI == VITM_EPI_BIAS) {
-    if (b.img != nullptr) {   // patch embedding: A gathered from the image
-      int rc = launch_one<EPI, 8, false, false, true>(b, grid, st);
-      if (rc != VITM_OK || !b.share) return rc;
-      switch (S) {
-        case 2: return launch_one<EPI, 4, true, false, true>(b, grid, st);
-        case 3: return launch_one<EPI, 3, true, false, true>(b, grid, st);
-        default: return launch_one<EPI, 2, true, false, true>(b, grid, st);
-      }
-    }
+    if (b.img != nullptr)   // patch embedding: A gathered from the image
+      return b.share ? launch_shared<EPI, false, true>(b, grid, S, st) : launch_one<EPI, 8, false, true>(b, grid, st);
   }
-  int rc = launch_one<EPI, 8, false>(b, grid, st);
-  if (rc != VITM_OK || !b.share) return rc;
-  switch (S) {
-    case 2: return launch_one<EPI, 4, true>(b, grid, st);
-    case 3: return launch_one<EPI, 3, true>(b, grid, st);
-    default: return launch_one<EPI, 2, true>(b, grid, st);
-  }
+  return b.share ? launch_shared<EPI, false, false>(b, grid, S, st) : launch_one<EPI, 8>(b, grid, st);
 }
 
 }  // namespace
