@@ -130,9 +130,9 @@ int vitm_patch_embed(const void* img, int img_dtype, int B, int C, int H, int W,
 
 /*
  * 1 when vitm_gemm (bf16 output, row_group 0) runs this shape on the persistent 256x256-tile kernel, 0 when on
- * the 128x128 one.  Lets a caller decide between vitm_patch_embed (im2col fused into the 128x128 kernel's tile
- * loader: right for small batches) and vitm_im2col + vitm_gemm (one extra pass over the patches, then the
- * faster kernel: right for large ones).
+ * the 128x128 one.  vitm_patch_embed gathers the patches in the tile loader of either kernel for bf16 images with a
+ * power-of-two patch width; for other inputs it always takes the 128x128 one, and a caller with a large batch does
+ * better with vitm_im2col + vitm_gemm (one extra pass over the patches, then the faster kernel).
  */
 int vitm_gemm_uses_big_tile(int M, int N, int K);
 
@@ -170,6 +170,17 @@ int vitm_patch_embed_f32(const void* img, int img_dtype, int B, int C, int H, in
 int vitm_embed_finalize(void* x, int x_dtype, int64_t ldx, int B, int ntok, int D, const float* cls,
                         const float* pos, const float* en_w, const float* en_b, float en_eps,
                         const float* np_w, const float* np_b, float np_eps, vitm_stream_t stream);
+
+/*
+ * vitm_embed_finalize that also leaves stats[m] = (mean, 1/sqrt(var + stats_eps)) of every finished row (the layout of
+ * vitm_ln_stats, and the same numbers: they are taken from the values as stored, i.e. after rounding to bf16 when x is
+ * bf16): the LayerNorm folded into the first GEMM that reads x (norm1 of block 0, models.py:209) then needs no pass of
+ * its own.  stats may be null.
+ */
+int vitm_embed_finalize_stats(void* x, int x_dtype, int64_t ldx, int B, int ntok, int D, const float* cls,
+                              const float* pos, const float* en_w, const float* en_b, float en_eps,
+                              const float* np_w, const float* np_b, float np_eps, float* stats,
+                              float stats_eps, vitm_stream_t stream);
 
 /*
  * Fused multi-head self-attention on a packed qkv activation: qkv is (B*N, 3*D) bf16 laid out as

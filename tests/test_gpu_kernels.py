@@ -343,6 +343,13 @@ def test_embed_finalize_and_layernorm(ops):
     t[:, 0] = cls
     ref = F.layer_norm(t, (D,), nw, nb, 1e-5) + pos
     _close(x.view(B, N, D), ref, rel=6e-3, what="embed_finalize")
+    # the same call also leaving the LayerNorm statistics of the finished rows
+    x2 = tok.clone()
+    st = torch.full((B * N, 2), float("nan"), device=DEV)
+    ops.embed_finalize(x2, B, N, D, cls, pos, ew, eb, 1e-5, nw, nb, 1e-5, stats=st, stats_eps=1e-6)
+    assert torch.equal(x2, x)
+    st_ref = ops.ln_stats(x2, B * N, D, 1e-6)   # the statistics are those of the rows as stored
+    assert torch.equal(st, st_ref)
     # pos only
     x = tok.clone()
     ops.embed_finalize(x, B, N, D, cls, pos, None, None, 0.0, None, None, 0.0)

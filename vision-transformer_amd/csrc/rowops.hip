@@ -141,7 +141,8 @@ __global__ __launch_bounds__(256) void embed_finalize_kernel(T* __restrict__ x, 
                                                              const float* __restrict__ en_w,
                                                              const float* __restrict__ en_b, float en_eps,
                                                              const float* __restrict__ np_w,
-                                                             const float* __restrict__ np_b, float np_eps) {
+                                                             const float* __restrict__ np_b, float np_eps,
+                                                             float* __restrict__ stats, float stats_eps) {
   const int lane = threadIdx.x & 63;
   const int m = blockIdx.x * ROWS_PER_WG + (threadIdx.x >> 6);
   if (m >= rows) return;
@@ -174,6 +175,16 @@ __global__ __launch_bounds__(256) void embed_finalize_kernel(T* __restrict__ x, 
       }
       store8(xr + c, r.v[t]);
     }
+  }
+  if (stats != nullptr) {   // (mean, rstd) of the row as stored, for the LayerNorm folded into the first GEMM that reads x
+    if (sizeof(T) == 2) {   // bf16 storage: the statistics are those of the rounded values, exactly what vitm_ln_stats sees
+#pragma unroll
+      for (int t = 0; t < NC; ++t)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) r.v[t][e] = bf2f(f2bf(r.v[t][e]));
+    }
+    row_stats(r, D, lane, stats_eps, mean, rstd);
+    if (lane == 0) *(float2*)(stats + 2 * (int64_t)m) = make_float2(mean, rstd);
   }
 }
 
@@ -461,10 +472,12 @@ extern "C" int vitm_layernorm(const void* x, int x_dtype, int64_t ldx, void* out
   return VITM_OK;
 }
 
-extern "C" int vitm_embed_finalize(void* x, int x_dtype, int64_t ldx, int B, int ntok, int D, const float* cls,
-                                   const float* pos, const float* en_w, const float* en_b, float en_eps,
-                                   const float* np_w, const float* np_b, float np_eps, vitm_stream_t stream) {
+extern "C" int vitm_embed_finalize_stats(void* x, int x_dtype, int64_t ldx, int B, int ntok, int D, const float* cls,
+                                         const float* pos, const float* en_w, const float* en_b, float en_eps,
+                                         const float* np_w, const float* np_b, float np_eps, float* stats,
+                                         float stats_eps, vitm_stream_t stream) {
   VITM_REQUIRE(x, "vitm_embed_finalize: null x");
+  VITM_REQUIRE(stats == nullptr || (((uintptr_t)stats & 7) == 0 && stats_eps > 0.f), "vitm_embed_finalize_stats: stats alignment / eps");
   VITM_REQUIRE(x_dtype == VITM_BF16 || x_dtype == VITM_F32, "vitm_embed_finalize: bad x_dtype %d", x_dtype);
   VITM_REQUIRE(B > 0 && ntok > 0 && D > 0 && D % 8 == 0 && D <= MAXD, "vitm_embed_finalize: D=%d must be a multiple of 8 and <= %d", D, MAXD);
   VITM_REQUIRE(ldx >= D && ldx % 8 == 0 && al16(x), "vitm_embed_finalize: ldx/alignment");
@@ -474,7 +487,7 @@ extern "C" int vitm_embed_finalize(void* x, int x_dtype, int64_t ldx, int B, int
   const int rows = B * ntok;
 #define VITM_EF_LAUNCH(T, NC)                                                                                          \
   hipLaunchKernelGGL((embed_finalize_kernel<T, NC>), dim3(row_grid(rows)), dim3(256), 0, (hipStream_t)stream, (T*)x, ldx, \
-                     rows, ntok, D, cls, pos, en_w, en_b, en_eps, np_w, np_b, np_eps)
+                     rows, ntok, D, cls, pos, en_w, en_b, en_eps, np_w, np_b, np_eps, stats, stats_eps)
   if (x_dtype == VITM_BF16) {
     if (D > MAXD_SMALL) VITM_EF_LAUNCH(bf16_t, NC_WIDE);
     else VITM_EF_LAUNCH(bf16_t, NC_SMALL);
@@ -485,6 +498,13 @@ extern "C" int vitm_embed_finalize(void* x, int x_dtype, int64_t ldx, int B, int
 #undef VITM_EF_LAUNCH
   VITM_CHECK_LAUNCH("vitm_embed_finalize");
   return VITM_OK;
+}
+
+extern "C" int vitm_embed_finalize(void* x, int x_dtype, int64_t ldx, int B, int ntok, int D, const float* cls,
+                                   const float* pos, const float* en_w, const float* en_b, float en_eps,
+                                   const float* np_w, const float* np_b, float np_eps, vitm_stream_t stream) {
+  return vitm_embed_finalize_stats(x, x_dtype, ldx, B, ntok, D, cls, pos, en_w, en_b, en_eps, np_w, np_b, np_eps, nullptr,
+                                   0.f, stream);
 }
 
 extern "C" int vitm_qk_norm(void* qkv, int dtype, int64_t ldqkv, int M, int H, int head_dim, const float* q_w,

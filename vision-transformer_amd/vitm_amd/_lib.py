@@ -49,6 +49,8 @@ SIGNATURES = {
                                      c_int, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
     "vitm_embed_finalize": (c_int, [c_void_p, c_int, c_int64, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                     c_float, c_void_p, c_void_p, c_float, c_void_p]),
+    "vitm_embed_finalize_stats": (c_int, [c_void_p, c_int, c_int64, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                          c_void_p, c_float, c_void_p, c_void_p, c_float, c_void_p, c_float, c_void_p]),
     "vitm_attention": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "vitm_qk_norm": (c_int, [c_void_p, c_int, c_int64, c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p,
                              c_void_p, c_float, c_void_p]),

@@ -228,10 +228,12 @@ def patch_embed(img: torch.Tensor, pk: PackedLinear, tokens: torch.Tensor, patch
         tokens.stride(0), D, 1 if cls_slot else 0, _stream()), "vitm_patch_embed")
 
 
-def embed_finalize(x: torch.Tensor, B: int, ntok: int, D: int, cls, pos, en_w, en_b, en_eps, np_w, np_b, np_eps) -> None:
-    _lib.check(_lib.load().vitm_embed_finalize(
+def embed_finalize(x: torch.Tensor, B: int, ntok: int, D: int, cls, pos, en_w, en_b, en_eps, np_w, np_b, np_eps,
+                   stats: Optional[torch.Tensor] = None, stats_eps: float = 0.0) -> None:
+    """``stats`` ([B*ntok, 2] fp32): also leave (mean, rstd) of the finished rows, as vitm_ln_stats would."""
+    _lib.check(_lib.load().vitm_embed_finalize_stats(
         _p(x), _dt(x), x.stride(0), B, ntok, D, _p(cls), _p(pos), _p(en_w), _p(en_b), float(en_eps), _p(np_w), _p(np_b),
-        float(np_eps), _stream()), "vitm_embed_finalize")
+        float(np_eps), _p(stats), float(stats_eps), _stream()), "vitm_embed_finalize")
 
 
 def attention(qkv: torch.Tensor, out: torch.Tensor, B: int, N: int, H: int, hd: int, scale: float) -> None:

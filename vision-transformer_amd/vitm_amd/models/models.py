@@ -312,7 +312,8 @@ class Block(nn.Module):
             _ops.gemm(x2d, attn._qkv_pack(dt, ln1), ws["qkv"], _ops.EPI_LN, M, stats=ws["carried"], stats_partial=True,
                       ln_eps=ln1[2])
         else:
-            _ops.ln_stats(x2d, M, D, ln1[2], ws["stats"])
+            if not ws.pop("stats_valid", False):   # True: the producer of x2d (embed_finalize) already left them
+                _ops.ln_stats(x2d, M, D, ln1[2], ws["stats"])
             _ops.gemm(x2d, attn._qkv_pack(dt, ln1), ws["qkv"], _ops.EPI_LN, M, stats=ws["stats"])
         attn._core(ws["qkv"], ws["o"], B, N)
         _ops.gemm(ws["o"], proj_pk, x2d, _ops.EPI_RESIDUAL, M, resid=x2d, stats_out=ws["carried"] if carry else None)
@@ -437,8 +438,9 @@ class VisionTransformer(nn.Module):
         pass  # a no-op in the reference as well (models.py:399-406)
 
     # ---- HIP path --------------------------------------------------------------------------------
-    def _features2d(self, x: torch.Tensor):
-        """forward_features on the residual-stream buffer: returns (x2d [B*N, ld] in x's dtype, B, N, D)."""
+    def _features2d(self, x: torch.Tensor, stats: Optional[torch.Tensor] = None, stats_eps: float = 0.0):
+        """forward_features on the residual-stream buffer: returns (x2d [B*N, ld] in x's dtype, B, N, D).  ``stats``
+        ([B*N, 2] fp32) also receives the LayerNorm statistics of the finished rows (eps ``stats_eps``)."""
         pe = self.patch_embed
         if not isinstance(pe, PatchEmbed) or not pe.flatten:
             raise NotImplementedError("the HIP path needs this package's PatchEmbed with flatten=True as embed_layer")
@@ -458,13 +460,24 @@ class VisionTransformer(nn.Module):
         _ops.embed_finalize(
             x2d, B, N, D, f(self.class_token).reshape(-1) if has_cls else None, f(self.pos_embed).reshape(N, D),
             f(en[0]) if en else None, f(en[1]) if en else None, en[2] if en else 0.0,
-            f(npre[0]) if npre else None, f(npre[1]) if npre else None, npre[2] if npre else 0.0)
+            f(npre[0]) if npre else None, f(npre[1]) if npre else None, npre[2] if npre else 0.0,
+            stats=stats, stats_eps=stats_eps)
         return x2d, B, N, D
 
     def _run_blocks(self, x: torch.Tensor):
         """Everything up to (not including) ``norm_final``; returns (x2d, B, N, D)."""
-        x2d, B, N, D = self._features2d(x)
         ws = None
+        first = self.blocks[0] if len(self.blocks) else None
+        if type(first) is Block and _ops.compute_dtype(x) == torch.bfloat16 and isinstance(self.patch_embed, PatchEmbed):
+            # bf16: the kernel that finishes the embedding also leaves the row statistics norm1 of block 0 needs
+            ln1 = layernorm_params(first.norm1, "Block.norm1")
+            if ln1 is not None:
+                Ntok = self.patch_embed.num_patches + (1 if self.class_token is not None else 0)
+                ws = first._workspace(x.shape[0] * Ntok, x.device, torch.bfloat16)
+                x2d, B, N, D = self._features2d(x, stats=ws["stats"], stats_eps=ln1[2])
+                ws["stats_valid"] = True
+        if ws is None:
+            x2d, B, N, D = self._features2d(x)
         for blk in self.blocks:
             if not hasattr(blk, "_run"):
                 raise NotImplementedError(f"block_fn {type(blk).__name__} has no HIP forward")
