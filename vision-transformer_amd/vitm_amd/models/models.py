@@ -260,10 +260,11 @@ class Block(nn.Module):
 
     Attention is built with the reference's defaults (no qkv bias, proj bias, no qk-norm, models.py:190-194) and
     the MLP with biases on both layers and ``hidden = int(dim * mlp_ratio)`` (models.py:198-205).
-    On the bf16 path a block is seven launches: LN statistics, LN-folded qkv GEMM, fused attention, proj GEMM with
-    bias + LayerScale + residual, LN statistics, LN-folded fc1 GEMM with GELU, fc2 GEMM with bias + LayerScale +
-    residual.  The fp32 path has the same seven with a full LayerNorm in place of the statistics pass (the fp32
-    GEMM does not fold it).
+    On the bf16 path at large batch a block is five launches: LN-folded qkv GEMM, fused attention, proj GEMM with
+    bias + LayerScale + residual, LN-folded fc1 GEMM with GELU, fc2 GEMM with bias + LayerScale + residual; the proj
+    and fc2 epilogues also leave the row moments that the next LayerNorm-folded GEMM turns into mean and rstd.  At
+    small batch (128x128-tile GEMMs) a LayerNorm-statistics launch precedes each folded GEMM: seven launches.  The
+    fp32 path has those seven with a full LayerNorm in place of the statistics pass (the fp32 GEMM does not fold it).
     """
 
     def __init__(self, dim: int, num_heads: int, mlp_ratio: float, norm_layer: Type[nn.Module] = nn.LayerNorm,
