@@ -86,6 +86,15 @@ def build_model(cfg, device, seed=0):
     return m.to(device).to(torch.bfloat16), sd
 
 
+
+def flops_per_image(shp: dict) -> float:
+    """Algorithmic FLOPs (MAC = 2) of one classification forward; LayerNorm / softmax / GELU excluded:
+    2 (N-1) K_pe D + L (2 N D 3D + 4 N^2 D + 2 N D^2 + 4 N D hid) + 2 D C."""
+    N, D, L = shp["tokens"], shp["embed_dim"], shp["depth"]
+    hid, C, kpe = shp["hidden"], shp.get("num_classes", 0), shp["k_pe"]
+    return (2.0 * (N - 1) * kpe * D + L * (2.0 * N * D * 3 * D + 4.0 * N * N * D + 2.0 * N * D * D + 4.0 * N * D * hid)
+            + 2.0 * D * C)
+
 def cpu_baseline(cfg, sd, budget_s=15.0, batch=8):
     """fp32 CPU oracle on `batch` images per pass, as many passes as fit the time budget (>= 2)."""
     from oracle import vit_oracle as O
@@ -138,7 +147,6 @@ def fc1_kernel_time(model, x, steps):
 def train_bench(args, world, rank, dist, dev):
     """Informational: images/sec of the training step -- fp32 (the reference trains in fp32) or, with --dtype bf16,
     mixed precision -- data-parallel over the ranks with the gradient all-reduce on RCCL.  Not the headline metric."""
-    from oracle.vit_oracle import flops_per_image
     from vitm_amd import training
     from vitm_amd.sharding import max_over_ranks
     cfg = W.CONFIGS[args.config]
@@ -307,7 +315,6 @@ def main():
         return train_bench(args, world, rank, dist, dev)
     cfg = W.CONFIGS[args.config]
     shp = W.shapes(cfg)
-    from oracle.vit_oracle import flops_per_image
     gflop_img = flops_per_image(shp) / 1e9
 
     model, sd = build_model(cfg, dev)
