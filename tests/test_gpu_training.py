@@ -463,3 +463,37 @@ def test_trainer_with_a_frozen_parameter():
     for k, p in m.named_parameters():
         if k in frozen:
             assert torch.equal(p.detach(), frozen[k]) and p.grad is None
+
+
+def test_gradient_reducer_on_rccl_single_rank():
+    """The RCCL leg of the data-parallel step on the one GPU at hand: a one-rank nccl group with the reducer forced on
+    (bucketed asynchronous all-reduces with ReduceOp.AVG over slices of the flat gradient buffer, the parameter broadcast,
+    the waits before clipping).  An average over one replica is the identity, so three steps must reproduce the steps
+    of a Trainer without a group bit for bit; a mis-ordered collective (reducing a slice before the backward kernels
+    that fill it have run, or clipping before the reduction has landed) would not."""
+    import socket
+    import torch.distributed as dist
+    from vitm_amd import training
+    if dist.is_initialized():
+        pytest.skip("a process group already exists in this process")
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                            device_id=torch.device("cuda", torch.cuda.current_device()))
+    try:
+        cfg = W.CONFIGS["tiny2"]
+        runs = []
+        for single in (False, True):
+            m = _model(cfg, 8)
+            opt = training.AdamW(m.parameters(), lr=1e-3)
+            tr = training.Trainer(m, opt, None, max_norm=1.0, group=dist.group.WORLD, bucket_bytes=64 << 10,
+                                  reduce_single_rank=single)
+            assert tr.reducer.active == single and (not single or tr.reducer.avg)
+            losses = [tr.step(*_batch(cfg, 4, 500 + i)).item() for i in range(3)]
+            runs.append((losses, [p.detach().clone() for p in m.parameters()]))
+        assert runs[0][0] == runs[1][0]
+        for a, b in zip(runs[0][1], runs[1][1]):
+            assert torch.equal(a, b)
+    finally:
+        dist.destroy_process_group()

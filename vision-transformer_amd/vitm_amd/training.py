@@ -568,10 +568,13 @@ class GradientReducer:
     point-to-point xGMI links a collective is per-link bound, so buckets are tens of MB, not the 1 MB of NVSwitch
     habits."""
 
-    def __init__(self, grads: "FlatGradients", group=None, bucket_bytes: int = 64 << 20):
+    def __init__(self, grads: "FlatGradients", group=None, bucket_bytes: int = 64 << 20, single_rank: bool = False):
+        """``single_rank``: run the collectives even in a group of one rank (an average over one replica changes
+        nothing; it lets one GPU rehearse the bucketing, the stream ordering and the RCCL calls)."""
         import torch.distributed as dist
         self.grads, self.group, self.bucket = grads, group, int(bucket_bytes)
-        self.active = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        self.active = (dist.is_available() and dist.is_initialized()
+                       and (dist.get_world_size(group) > 1 or bool(single_rank)))
         self.world = dist.get_world_size(group) if self.active else 1
         self.avg = self.active and dist.get_backend(group) == "nccl"
         self.offset = {p: o for p, o in zip(grads.params, grads.offsets)}
@@ -760,7 +763,7 @@ class Trainer:
     """One object for the loop body of train.py:215-224 (plus the data-parallel all-reduce)."""
 
     def __init__(self, model, optimizer, scheduler=None, max_norm: float = 1.0, group=None,
-                 compute_dtype: Optional[torch.dtype] = None, bucket_bytes: int = 64 << 20):
+                 compute_dtype: Optional[torch.dtype] = None, bucket_bytes: int = 64 << 20, reduce_single_rank: bool = False):
         self.model, self.optimizer, self.scheduler, self.max_norm, self.group = model, optimizer, scheduler, max_norm, group
         self.compute_dtype = compute_dtype          # None: follow the images (fp32 images -> fp32, bf16 -> mixed precision)
         self.grads = FlatGradients(model.parameters())
@@ -771,7 +774,7 @@ class Trainer:
                 self.params = flat
         self.criterion = CrossEntropyLoss()
         self.last_grad_norm = None
-        self.reducer = GradientReducer(self.grads, group, bucket_bytes)
+        self.reducer = GradientReducer(self.grads, group, bucket_bytes, single_rank=reduce_single_rank)
         if self.reducer.active:
             self.sync_from_rank0()
 
