@@ -282,6 +282,9 @@ def main():
                     help="train: one training step per step (forward, loss, backward, all-reduce, clip, AdamW)")
     ap.add_argument("--dtype", default=None, choices=["bf16", "f32"],
                     help="training arithmetic (default f32, the reference's); the forward benchmark is bf16")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="create the nccl process group even for one rank: rehearses the barrier / gather / max-over-ranks "
+                         "path on RCCL with the one GPU at hand")
     ap.add_argument("--selftest-launch", action="store_true",
                     help="rehearse the multi-rank launch on CPU (gloo) around a no-op step; no GPU is touched")
     args = ap.parse_args()
@@ -301,9 +304,12 @@ def main():
             import torch.distributed as dist
             dist.init_process_group(backend="gloo")
         sys.exit(selftest_launch(args, world, rank, dist))
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
+        if "MASTER_ADDR" not in os.environ:      # --force-dist outside a launcher
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=os.environ.get("MASTER_PORT", "29531"), RANK="0",
+                              WORLD_SIZE="1")
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         if dist.get_world_size() != args.gpus:
             raise SystemExit(f"process group has {dist.get_world_size()} ranks, --gpus {args.gpus}")
