@@ -329,6 +329,39 @@ def test_row_kernels_wide_rows(ops, D):
     _close(y.view(Bn, N, D), F.layer_norm(t, (D,), w, b, 1e-5) + pos, rel=6e-3, what="wide embed_finalize")
 
 
+@pytest.mark.parametrize("C,H,Wd,ph,pw,D,B", [(3, 96, 96, 32, 32, 256, 3700),    # K = 3072, 9 patches per image
+                                              (1, 64, 128, 16, 16, 256, 1100),    # one channel, non-square image
+                                              (3, 32, 64, 8, 16, 512, 2100),      # non-square patch: K = 384
+                                              (4, 48, 48, 4, 8, 256, 1000),       # 64 / pw = 8 image rows per K-tile > ph
+                                              (2, 64, 64, 2, 64, 256, 1100)])     # a K-tile is one patch row
+def test_patch_embed_gathering_loader_shapes(ops, C, H, Wd, ph, pw, D, B):
+    """The big-tile kernel's gathering loader against the patch-matrix route (same kernel fed from memory), bit for
+    bit, on patch / image / channel shapes that stress its address arithmetic; and against the oracle's im2col."""
+    from oracle import vit_oracle as O
+    from vitm_amd import _lib
+    x = _bf(_rand(B, C, H, Wd, seed=80))
+    w = _rand(D, C, ph, pw, seed=81, scale=(C * ph * pw) ** -0.5)
+    b = _rand(D, seed=82, scale=0.1)
+    pk = ops.pack_linear(w, b)
+    Np = (H // ph) * (Wd // pw)
+    assert pk.kpad == C * ph * pw and _lib.load().vitm_gemm_uses_big_tile(B * Np, pk.npad, pk.kpad) == 1
+    for cls_slot in (False, True):
+        rows = B * (Np + int(cls_slot))
+        tok = torch.full((rows, D), 7.0, dtype=torch.bfloat16, device=DEV)
+        ops.patch_embed(x, pk, tok, (ph, pw), D, cls_slot)
+        got = tok.view(B, Np + int(cls_slot), D)
+        if cls_slot:
+            assert (got[:, 0] == 7.0).all(), "class-token slot must be left untouched"
+            got = got[:, 1:]
+        A = torch.empty((rows, pk.kpad), dtype=torch.bfloat16, device=DEV)
+        ops.im2col(x, A, (ph, pw), pk.kpad, cls_slot)
+        tok2 = torch.empty((rows, D), dtype=torch.bfloat16, device=DEV)
+        ops.gemm(A, pk, tok2, ops.EPI_BIAS, rows)
+        assert torch.equal(got, tok2.view(B, Np + int(cls_slot), D)[:, int(cls_slot):]), "gathered != patch-matrix route"
+        cols = O.im2col(x[:8].float().cpu(), (ph, pw)).to(DEV)
+        _close(got[:8], cols @ _bf(w).float().reshape(D, -1).t() + b, what="gathering loader vs oracle im2col")
+
+
 def test_embed_finalize_and_layernorm(ops):
     B, N, D = 3, 65, 192
     tok = _bf(_rand(B * N, D, seed=25))

@@ -335,7 +335,7 @@ extern "C" int vitm_patch_embed(const void* img, int img_dtype, int B, int C, in
   // addresses (no patch matrix in memory).  Its rows include the class-token slots, so the row map is the identity.
   const int rows = B * (gh * gw + (cls_slot ? 1 : 0));
   if (img_dtype == VITM_BF16 && vec_ok && kreal == kpad && (pw & (pw - 1)) == 0 && pw <= BK &&
-      vitm_gemm_pp_wanted(rows, D, kpad) && (int64_t)B * C * H * W < (1ll << 31)) {
+      vitm_gemm_pp_wanted(rows, D, kpad) && (int64_t)C * H * W < (1ll << 31)) {   // per-image offsets are 32-bit
     GemmArgs b = a;
     b.M = rows; b.row_group = 0; b.cls = cls_slot ? 1 : 0;
     b.pw_shift = __builtin_ctz((unsigned)pw);
