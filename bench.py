@@ -365,12 +365,13 @@ def main():
     assert torch.isfinite(out.float()).all()
 
     # per round the slowest rank's time; the line reports the median round
-    rounds = [max_over_ranks(r, dist, dev) for r in rounds]
+    own_rounds = rounds
+    rounds = [max_over_ranks(r, dist, dev) for r in own_rounds]
     order = sorted(range(len(rounds)), key=lambda i: rounds[i])
     med = order[len(order) // 2]
     elapsed = rounds[med]
     ranks_seen = dist.get_world_size() if dist is not None else 1
-    per_rank = gather_floats(args.batch * args.steps / elapsed, dist, dev)   # each rank at the median round's clock
+    per_rank = gather_floats(args.batch * args.steps / own_rounds[med], dist, dev)   # each rank's own clock, median round
 
     line = None
     if rank == 0:
