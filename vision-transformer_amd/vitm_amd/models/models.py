@@ -299,8 +299,13 @@ class Block(nn.Module):
         # says whether it describes the current x2d -- the first block of a forward starts from vitm_ln_stats)
         proj_pk = attn._proj_pack(dt, self.ls1.gamma)
         fc2_pk = mlp._fc2_pack(dt, self.ls2.gamma)
-        carry = (CARRY_LN_STATS and not f32 and ln1 is not None and ln2 is not None and D <= 256 * _ops._lib.STATS_PARTS
-                 and all(_ops.uses_big_tile(M, pk) for pk in (proj_pk, fc2_pk, attn._qkv_pack(dt, ln1), mlp._fc1_pack(dt, ln2))))
+        carry = False
+        if CARRY_LN_STATS and not f32 and ln1 is not None and ln2 is not None and D <= 256 * _ops._lib.STATS_PARTS:
+            memo = self.__dict__.setdefault("_vitm_carry", {})   # the route depends on the shapes only
+            carry = memo.get(M)
+            if carry is None:
+                carry = memo[M] = all(_ops.uses_big_tile(M, pk) for pk in
+                                      (proj_pk, fc2_pk, attn._qkv_pack(dt, ln1), mlp._fc1_pack(dt, ln2)))
         if carry and "carried" not in ws:
             ws["carried"] = _ops.carried_stats(M, D, x2d.device)
             ws["carried_valid"] = False
