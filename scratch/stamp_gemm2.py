@@ -20,7 +20,7 @@ def stamp(name, N, K, epi):
     if PW:
         wp = torch.zeros((pk.wp.shape[0], pk.kpad + PW), dtype=pk.wp.dtype, device="cuda"); wp[:, :pk.kpad] = pk.wp
     out = torch.empty((M, N), dtype=torch.bfloat16, device="cuda")
-    dbg = torch.zeros((256, 12, 8), dtype=torch.int64, device="cuda")
+    dbg = torch.zeros((256, 12, 20), dtype=torch.int64, device="cuda")
     def run():
         _lib.check(lib.vitm_gemm(ops._p(A), K + PA, ops._p(wp), pk.kpad + PW, ops._p(out), N, 0, M, N, K, epi, ops._p(stats), ops._p(pk.s), ops._p(pk.c), None, ops._p(dbg), N, 0, ops._stream()), "gemm")
     for _ in range(20): run()
@@ -35,6 +35,9 @@ def stamp(name, N, K, epi):
     gap = d[:, 1:nt, 0] - d[:, :nt-1, 2]
     k0 = d[:, :nt, 4] - d[:, :nt, 0]; k1 = d[:, :nt, 5] - d[:, :nt, 4]; k2 = d[:, :nt, 6] - d[:, :nt, 5]
     rest = (d[:, :nt, 1] - d[:, :nt, 6]) / (K // 64 - 3)
+    nkt = min(K // 64, 16)
+    per = np.stack([d[:, 1:nt - 1, 4 + t] - (d[:, 1:nt - 1, 4 + t - 1] if t else d[:, 1:nt - 1, 0]) for t in range(nkt)], -1)
+    if nt > 2: print("every K-tile of the middle tiles (median cycles):", np.median(per.reshape(-1, nkt), 0).astype(int))
     print(f"== pad A {PA} W {PW} {name} N={N} K={K} epi={epi} tiles={tiles} whole rounds stamped={nt}")
     print("median K-loop cycles per tile index:", np.median(ml, 0).astype(int))
     print("median epilogue cycles per tile index:", np.median(ep, 0).astype(int))

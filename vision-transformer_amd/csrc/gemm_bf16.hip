@@ -275,7 +275,8 @@ static int gemm_impl(const void* A, int64_t lda, const void* Wp, int64_t ldw, vo
   VITM_REQUIRE(epilogue != VITM_EPI_DGELU || (resid && aligned16(resid) && ldr >= N && ldr % 8 == 0 && out_dtype == VITM_BF16),
                "vitm_gemm: DGELU epilogue needs resid (the GELU input, ldr >= N, multiple of 8) and bf16 output");
   VITM_REQUIRE(row_group >= 0, "vitm_gemm: row_group must be >= 0");
-  const bool big = row_group == 0 && out_dtype == VITM_BF16 && vitm_gemm_pp_wanted(M, N, K);
+  // the big-tile kernel addresses a tile's operand rows by 32-bit byte offsets from the tile's first row
+  const bool big = row_group == 0 && out_dtype == VITM_BF16 && vitm_gemm_pp_wanted(M, N, K) && lda < (1 << 22) && ldw < (1 << 22);
   if (stats_out != nullptr || stats_partial) {
     VITM_REQUIRE(big, "vitm_gemm_stats: carried LayerNorm statistics need the 256x256-tile route (vitm_gemm_uses_big_tile)");
     VITM_REQUIRE(stats_out == nullptr || (epilogue == VITM_EPI_RESIDUAL && N <= VITM_STATS_PARTS * BN_BIG && aligned16(stats_out)),

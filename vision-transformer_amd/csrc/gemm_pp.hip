@@ -54,11 +54,12 @@
 #endif
 
 #ifdef PP_STAMP  // diagnostic build: thread 0 of each workgroup records s_memtime at phase boundaries into p.resid
+                 // (20 slots per tile: 0 tile start, 1 K loop end, 2 epilogue end, 3 realtime, 4 + t after K-tile t < 16)
 #define STAMP(k)                                                                                   \
   do {                                                                                             \
     unsigned long long t__;                                                                        \
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__)::"memory");                    \
-    if (!SLICE && tid == 0 && it < 12 && p.resid) ((unsigned long long*)p.resid)[((size_t)blockIdx.x * 12 + it) * 8 + (k)] = t__; \
+    if (!SLICE && tid == 0 && it < 12 && p.resid) ((unsigned long long*)p.resid)[((size_t)blockIdx.x * 12 + it) * 20 + (k)] = t__; \
   } while (0)
 #else
 #define STAMP(k) do {} while (0)
@@ -201,13 +202,22 @@ __device__ __forceinline__ void tile_loop(const GemmArgs& p, char* smem) {
   // Tile order: column bands of p.band N-tiles, row-major inside a band (the last band may be narrower).  The weight
   // rows of a band (band x 256 x K) fit an XCD's L2, so they are fetched once per XCD and band instead of once per
   // A row panel; the A panels are read once per band.
-  auto tile_mn = [&](int w, int& mt, int& nt) {
-    const int per_band = p.tilesM * p.band;
-    const int b = w / per_band, r = w - b * per_band;
-    int bw = p.tilesN - b * p.band;
-    bw = bw < p.band ? bw : p.band;
-    mt = r / bw;
-    nt = b * p.band + (r - mt * bw);
+  auto tile_mn = [&](int w, int& mt, int& nt) {   // unsigned: the divisions by run-time values are half as long
+    const unsigned per_band = (unsigned)p.tilesM * (unsigned)p.band;
+    const unsigned b = (unsigned)w / per_band, r = (unsigned)w - b * per_band;
+    unsigned bw = (unsigned)p.tilesN - b * (unsigned)p.band;
+    bw = bw < (unsigned)p.band ? bw : (unsigned)p.band;
+    const unsigned m = r / bw;
+    mt = (int)m;
+    nt = (int)(b * (unsigned)p.band + (r - m * bw));
+  };
+  // (mt, nt) of a tile of this workgroup's list, worked out once per tile and ahead of time: the DMA stream reaches
+  // the next tile in the last K-tiles of the current one, inside LOAD segments, where two run-time divisions (~700
+  // cycles of dependent scalar work, twice: A and W) used to sit on the critical path
+  int prep_it = -1, prep_mt = 0, prep_nt = 0;
+  auto prep_tile = [&](int it) {
+    tile_mn(tile_of(it), prep_mt, prep_nt);
+    prep_it = it;
   };
   const int nk = p.K / BK;
 
@@ -215,8 +225,15 @@ __device__ __forceinline__ void tile_loop(const GemmArgs& p, char* smem) {
   // 128 B; lane -> row lane>>3, physical chunk lane&7, logical chunk = physical ^ (row & 7)
   const int lr = lane >> 3;
   const int lc = (lane & 7) ^ lr;
-  const bf16_t* asrc[4];
-  const bf16_t* wsrc[4];
+  // operand addresses = a wave-uniform base (first row of the tile's rows) + a 32-bit per-lane element offset;
+  // the gathering loader keeps per-lane pointers (its rows belong to different images)
+  const bf16_t* asrc[IM2COL ? 4 : 1];
+  const char* abase = (const char*)p.A;
+  const char* wbase = (const char*)p.W;
+  // byte offsets of this lane's 16 bytes inside a tile's rows: the same for every tile except a ragged last one,
+  // whose rows past the end are clamped to the last row (a_rag / w_rag: the offsets currently hold clamped values)
+  unsigned aob[4], wob[4];
+  bool a_rag = true, w_rag = true;   // "true" forces the first set_a / set_w to fill the offsets
   // this wave's A pieces q = 0..3 carry blocks fa, fa, fa + 1, fa + 1 of its wave group's half; a slice moves only
   // the pieces [a_lo, a_hi) that lie in its block range (0, 2 or 4 of them)
   const int fa = 2 * (wave & 3);
@@ -239,16 +256,26 @@ __device__ __forceinline__ void tile_loop(const GemmArgs& p, char* smem) {
     }
   }
   auto set_a = [&](int it) {
-    int mt, nt;
-    tile_mn(tile_of(it), mt, nt);
-    const int am0 = mt * BM;
+    if (it != prep_it) prep_tile(it);
+    const int am0 = prep_mt * BM;
+    if constexpr (!IM2COL) {
+      abase = (const char*)(p.A + (int64_t)am0 * p.lda);
+      const bool rag = am0 + BM > p.M;
+      if (rag || a_rag) {   // wave-uniform and rare after the first tile
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          int r = (4 * wave + q) * 8 + lr;
+          r = am0 + r < p.M ? r : p.M - 1 - am0;
+          aob[q] = ((unsigned)r * (unsigned)p.lda + lc * 8) * 2u;
+        }
+      }
+      a_rag = rag;
+    }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       int am = am0 + (4 * wave + q) * 8 + lr;
       am = am < p.M ? am : p.M - 1;
-      if (!IM2COL) {
-        asrc[q] = p.A + (int64_t)am * p.lda + lc * 8;
-      } else {
+      if constexpr (IM2COL) {
         const int ntok = p.npatch + p.cls;
         const int b = am / ntok;
         int t = am - b * ntok - p.cls;       // a class-token slot reads patch 0; its output row is not stored
@@ -269,15 +296,19 @@ __device__ __forceinline__ void tile_loop(const GemmArgs& p, char* smem) {
     }
   };
   auto set_w = [&](int it) {
-    int mt, nt;
-    tile_mn(tile_of(it), mt, nt);
-    const int wn0 = nt * BN;
+    if (it != prep_it) prep_tile(it);
+    const int wn0 = prep_nt * BN;
+    wbase = (const char*)(p.W + (int64_t)wn0 * p.ldw);
+    const bool rag = wn0 + BN > p.N;
+    if (rag || w_rag) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      int wn = wn0 + (4 * wave + q) * 8 + lr;
-      wn = wn < p.N ? wn : p.N - 1;
-      wsrc[q] = p.W + (int64_t)wn * p.ldw + lc * 8;
+      for (int q = 0; q < 4; ++q) {
+        int r = (4 * wave + q) * 8 + lr;
+        r = wn0 + r < p.N ? r : p.N - 1 - wn0;
+        wob[q] = ((unsigned)r * (unsigned)p.ldw + lc * 8) * 2u;
+      }
     }
+    w_rag = rag;
   };
   set_a(0);
   set_w(0);
@@ -287,19 +318,24 @@ __device__ __forceinline__ void tile_loop(const GemmArgs& p, char* smem) {
     if (a_it >= ntl) return 0;
     char* sb = smem + a_slot * PART + 4 * wave * 1024;
     const int ao = IM2COL ? a_koff : a_t * BK;
+    const char* ab = abase + (size_t)a_t * (BK * 2);   // wave-uniform: the address is scalar base + 32-bit lane offset
+    auto src = [&](int q) -> const void* {
+      if constexpr (IM2COL) return asrc[q] + ao;
+      else return ab + aob[q];
+    };
     int n = 4;
     if (!SLICE) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) glds16(asrc[q] + ao, sb + q * 1024);
+      for (int q = 0; q < 4; ++q) glds16(src(q), sb + q * 1024);
     } else {
       n = a_hi - a_lo;
       if (a_lo == 0 && n >= 2) {
-        glds16(asrc[0] + ao, sb);
-        glds16(asrc[1] + ao, sb + 1024);
+        glds16(src(0), sb);
+        glds16(src(1), sb + 1024);
       }
       if (a_hi == 4 && n >= 2) {
-        glds16(asrc[2] + ao, sb + 2048);
-        glds16(asrc[3] + ao, sb + 3072);
+        glds16(src(2), sb + 2048);
+        glds16(src(3), sb + 3072);
       }
     }
     a_slot = a_slot == NA - 1 ? 0 : a_slot + 1;
@@ -315,8 +351,9 @@ __device__ __forceinline__ void tile_loop(const GemmArgs& p, char* smem) {
   auto issueA_half = [&](int half) -> int {
     if (a_it >= ntl) return 0;
     char* sb = smem + a_slot * PART + 4 * wave * 1024;
-    glds16(asrc[2 * half] + a_t * BK, sb + (2 * half) * 1024);
-    glds16(asrc[2 * half + 1] + a_t * BK, sb + (2 * half + 1) * 1024);
+    const char* ab = abase + (size_t)a_t * (BK * 2);
+    glds16(ab + aob[2 * half], sb + (2 * half) * 1024);
+    glds16(ab + aob[2 * half + 1], sb + (2 * half + 1) * 1024);
     if (half == 1) {
       a_slot = a_slot == NA - 1 ? 0 : a_slot + 1;
       if (++a_t == nk) {
@@ -329,8 +366,9 @@ __device__ __forceinline__ void tile_loop(const GemmArgs& p, char* smem) {
   auto issueW = [&]() {
     if (w_it >= ntl) return;
     char* sb = smem + WBASE + w_slot * PART + 4 * wave * 1024;
+    const char* wb = wbase + (size_t)w_t * (BK * 2);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) glds16(wsrc[q] + w_t * BK, sb + q * 1024);
+    for (int q = 0; q < 4; ++q) glds16(wb + wob[q], sb + q * 1024);
     w_slot ^= 1;
     if (++w_t == nk) {
       w_t = 0;
@@ -389,9 +427,10 @@ __device__ __forceinline__ void tile_loop(const GemmArgs& p, char* smem) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
+    if (it + 1 < ntl) prep_tile(it + 1);   // for the DMA stream, which gets there in this tile's last K-tiles
     STAMP(0);
 #ifdef PP_STAMP
-    if (!SLICE && tid == 0 && it < 12 && p.resid) ((unsigned long long*)p.resid)[((size_t)blockIdx.x * 12 + it) * 8 + 3] = __builtin_amdgcn_s_memrealtime();
+    if (!SLICE && tid == 0 && it < 12 && p.resid) ((unsigned long long*)p.resid)[((size_t)blockIdx.x * 12 + it) * 20 + 3] = __builtin_amdgcn_s_memrealtime();
 #endif
     if (grp == 1) seg_barrier();   // group 0's first LOAD of the tile
     for (int t = 0; t < nk; ++t) {
@@ -424,9 +463,7 @@ __device__ __forceinline__ void tile_loop(const GemmArgs& p, char* smem) {
       ca = ca == NA - 1 ? 0 : ca + 1;
       cw ^= 1;
 #ifdef PP_STAMP
-      if (t == 0) STAMP(4);
-      if (t == 1) STAMP(5);
-      if (t == 2) STAMP(6);
+      if (t < 16) STAMP(4 + t);   // after K-tile t
 #endif
     }
     if (grp == 0) seg_barrier();   // group 1's last COMPUTE of the tile
