@@ -53,13 +53,21 @@
 #define PP_ABLATE 0   // timing-only diagnostic builds (wrong results): 1 no DMA after the prologue, 4 no output stores
 #endif
 
-#ifdef PP_STAMP  // diagnostic build: thread 0 of each workgroup records s_memtime at phase boundaries into p.resid
-                 // (20 slots per tile: 0 tile start, 1 K loop end, 2 epilogue end, 3 realtime, 4 + t after K-tile t < 16)
+#ifdef PP_STAMP  // diagnostic build: s_memtime at phase boundaries into p.resid, 20 slots per record: 0 tile start,
+                 // 1 K loop end, 2 epilogue end, 3 realtime, 4 + t after K-tile t < 16.  -DPP_STAMP: one record per
+                 // (workgroup, tile), written by thread 0; -DPP_STAMP=2: one per (workgroup, tile, wave), by lane 0
+#if (PP_STAMP + 0) == 2
+#define STAMP_AT ((((size_t)blockIdx.x * 12 + it) * 8 + wave) * 20)
+#define STAMP_WHO (lane == 0)
+#else
+#define STAMP_AT (((size_t)blockIdx.x * 12 + it) * 20)
+#define STAMP_WHO (tid == 0)
+#endif
 #define STAMP(k)                                                                                   \
   do {                                                                                             \
     unsigned long long t__;                                                                        \
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__)::"memory");                    \
-    if (!SLICE && tid == 0 && it < 12 && p.resid) ((unsigned long long*)p.resid)[((size_t)blockIdx.x * 12 + it) * 20 + (k)] = t__; \
+    if (!SLICE && STAMP_WHO && it < 12 && p.resid) ((unsigned long long*)p.resid)[STAMP_AT + (k)] = t__; \
   } while (0)
 #else
 #define STAMP(k) do {} while (0)
@@ -417,9 +425,8 @@ __device__ __forceinline__ void tile_loop(const GemmArgs& p, char* smem) {
   const bool dma = (PP_ABLATE & 1) == 0;
 
   for (int it = 0; it < ntl; ++it) {
-    const int wgid = tile_of(it);
-    int mt_, nt_;
-    tile_mn(wgid, mt_, nt_);
+    if (it != prep_it) prep_tile(it);          // normally prepared while the previous tile ran
+    const int mt_ = prep_mt, nt_ = prep_nt;
     const int m0 = mt_ * BM;
     const int n0 = nt_ * BN;
 #pragma unroll
@@ -430,7 +437,7 @@ __device__ __forceinline__ void tile_loop(const GemmArgs& p, char* smem) {
     if (it + 1 < ntl) prep_tile(it + 1);   // for the DMA stream, which gets there in this tile's last K-tiles
     STAMP(0);
 #ifdef PP_STAMP
-    if (!SLICE && tid == 0 && it < 12 && p.resid) ((unsigned long long*)p.resid)[((size_t)blockIdx.x * 12 + it) * 20 + 3] = __builtin_amdgcn_s_memrealtime();
+    if (!SLICE && STAMP_WHO && it < 12 && p.resid) ((unsigned long long*)p.resid)[STAMP_AT + 3] = __builtin_amdgcn_s_memrealtime();
 #endif
     if (grp == 1) seg_barrier();   // group 0's first LOAD of the tile
     for (int t = 0; t < nk; ++t) {
