@@ -88,8 +88,10 @@ static_assert(SMEM <= 160 * 1024, "LDS budget");
 // an even 16-lane row holds (its own a, the a of lane+16) and a lane of an odd row (the b of lane-16, its own b).
 // Inline asm on purpose: with float operands hipcc (ROCm 7.2) folds the builtin's second result into the first.
 // The two v_nop are the wait states the instruction needs after a VALU write of its operands.
-__device__ __forceinline__ void swap16(unsigned& a, unsigned& b) {
-  asm volatile("v_nop\n\tv_nop\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+__device__ __forceinline__ void swap16(unsigned& a, unsigned& b) {   // integer operands: the builtin is compiled
+  const auto r = __builtin_amdgcn_permlane16_swap(a, b, false, false);   // correctly and places the wait states itself
+  a = r[0];
+  b = r[1];
 }
 __device__ __forceinline__ void swap16(float& a, float& b) {
   asm volatile("v_nop\n\tv_nop\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
@@ -108,12 +110,13 @@ __device__ __forceinline__ float ror8(float x) {   // the value of lane ^ 8
 // instruction covers 8 rows x 128 contiguous bytes (whole cache lines) instead of 16 rows x 64 bytes.  In: x0 / x1
 // = this lane's row, columns [c, c+8) / [c+32, c+40).  Out: x0 goes to row (r&7) and x1 to row 8+(r&7), both at
 // columns c + (r >= 8 ? 32 : 0).
-__device__ __forceinline__ void rowpair_exchange1(unsigned& x0, unsigned& x1, bool hi8) {
-  const unsigned t = hi8 ? x0 : x1;
-  const unsigned r = __builtin_amdgcn_update_dpp(0u, t, 0x128, 0xf, 0xf, false);   // row_ror:8 -> value of lane ^ 8
-  const unsigned a = hi8 ? r : x0, b = hi8 ? x1 : r;
-  x0 = a;
-  x1 = b;
+__device__ __forceinline__ void rowpair_exchange1(unsigned& x0, unsigned& x1, bool /*hi8*/) {
+  // two DPP moves whose bank masks pick the receiving lanes (a 16-lane row has four banks of four lanes; lanes 8-15 =
+  // banks 2, 3): lanes 8-15 take x1 of lane ^ 8 as their x0, lanes 0-7 take x0 of lane ^ 8 as their x1
+  const unsigned n0 = __builtin_amdgcn_update_dpp(x0, x1, 0x128, 0xf, 0xc, false);   // row_ror:8 -> value of lane ^ 8
+  const unsigned n1 = __builtin_amdgcn_update_dpp(x1, x0, 0x128, 0xf, 0x3, false);
+  x0 = n0;
+  x1 = n1;
 }
 __device__ __forceinline__ void rowpair_exchange(uint4& x0, uint4& x1, bool hi8) {
   rowpair_exchange1(x0.x, x1.x, hi8);
