@@ -86,15 +86,18 @@ static_assert(SMEM <= 160 * 1024, "LDS budget");
 
 // v_permlane16_swap: lanes 16-31 / 48-63 of `a` trade places with lanes 0-15 / 32-47 of `b`.  Afterwards a lane of
 // an even 16-lane row holds (its own a, the a of lane+16) and a lane of an odd row (the b of lane-16, its own b).
-// Inline asm on purpose: with float operands hipcc (ROCm 7.2) folds the builtin's second result into the first.
-// The two v_nop are the wait states the instruction needs after a VALU write of its operands.
+// The builtin is used on unsigned operands only: fed float values cast on the fly, hipcc (ROCm 7.2) folded its second
+// result into the first; floats therefore go through explicit bit casts into unsigned variables first.
 __device__ __forceinline__ void swap16(unsigned& a, unsigned& b) {   // integer operands: the builtin is compiled
   const auto r = __builtin_amdgcn_permlane16_swap(a, b, false, false);   // correctly and places the wait states itself
   a = r[0];
   b = r[1];
 }
-__device__ __forceinline__ void swap16(float& a, float& b) {
-  asm volatile("v_nop\n\tv_nop\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+__device__ __forceinline__ void swap16(float& a, float& b) {   // through the integer form (see the note above)
+  unsigned ua = __builtin_bit_cast(unsigned, a), ub = __builtin_bit_cast(unsigned, b);
+  swap16(ua, ub);
+  a = __builtin_bit_cast(float, ua);
+  b = __builtin_bit_cast(float, ub);
 }
 
 // v_permlane32_swap: lanes 32-63 of `a` trade places with lanes 0-31 of `b`; afterwards a lane of the lower half holds
