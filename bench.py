@@ -288,6 +288,9 @@ def main():
     ap.add_argument("--selftest-launch", action="store_true",
                     help="rehearse the multi-rank launch on CPU (gloo) around a no-op step; no GPU is touched")
     args = ap.parse_args()
+    if os.environ.get("VITM_BENCH_WATCHDOG"):   # seconds; a run still alive then prints every thread's stack and exits
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["VITM_BENCH_WATCHDOG"]), exit=True)
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         # not under a launcher: start the ranks ourselves, before anything here initialises a GPU

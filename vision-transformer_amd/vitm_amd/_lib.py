@@ -127,10 +127,20 @@ def load() -> ctypes.CDLL:
     return _lib
 
 
+_SYNC_DEBUG = bool(os.environ.get("VITM_SYNC_DEBUG"))   # diagnosis of a hung launch: name every call, wait for it
+
+
 def check(status: int, what: str) -> None:
     if status != 0:
         msg = load().vitm_last_error().decode("utf-8", "replace")
         raise VitmError(f"{what} failed ({status}): {msg}")
+    if _SYNC_DEBUG:
+        import sys
+        import torch
+        sys.stderr.write(f"[vitm] {what} ...")
+        sys.stderr.flush()
+        torch.cuda.synchronize()
+        sys.stderr.write(" done\n")
 
 
 def version() -> str:
