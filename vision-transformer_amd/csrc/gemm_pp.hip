@@ -503,18 +503,36 @@ __device__ __forceinline__ void tile_loop(const GemmArgs& p, char* smem) {
     }
     float2 st[NBLK];
     if (EPI == VITM_EPI_LN || EPI == VITM_EPI_LN_GELU) {
+      // the (wave-uniform) layout test sits outside the row loop: inside it every row block became a basic block of
+      // its own, i.e. load, wait for everything in flight, combine, eight times in a row
+      if (!p.stats_partial) {
 #pragma unroll
-      for (int i = 0; i < NBLK; ++i) {
-        int m = mrow + 16 * i;
-        m = m < p.M ? m : p.M - 1;
-        if (!p.stats_partial) {
+        for (int i = 0; i < NBLK; ++i) {
+          int m = mrow + 16 * i;
+          m = m < p.M ? m : p.M - 1;
           st[i] = *(const float2*)(p.stats + 2 * (int64_t)m);
-        } else {   // raw moments per 256-column tile of the producing GEMM: combine, then mean and rstd
+        }
+      } else {
+        // raw moments per 256-column tile of the producing GEMM: combine, then mean and rstd.  The four 16-lane rows
+        // of a wave need the same 16 x NBLK output rows, so each takes two of the row blocks (4 loads instead of 16,
+        // a quarter of the arithmetic) and the results go round by cross-lane reads
+        float2 mine[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          int i = 2 * q4 + e;
+          i = i < NBLK ? i : NBLK - 1;
+          int m = mrow + 16 * i;
+          m = m < p.M ? m : p.M - 1;
           const float4 u = *(const float4*)(p.stats + 2 * VITM_STATS_PARTS * (int64_t)m);
           const float4 w = *(const float4*)(p.stats + 2 * VITM_STATS_PARTS * (int64_t)m + 4);
           const float mean = ((u.x + u.z) + (w.x + w.z)) * p.ln_inv_dim;
           const float var = fmaf(-mean, mean, ((u.y + u.w) + (w.y + w.w)) * p.ln_inv_dim);
-          st[i] = make_float2(mean, __builtin_amdgcn_rsqf(fmaxf(var, 0.f) + p.ln_eps));
+          mine[e] = make_float2(mean, __builtin_amdgcn_rsqf(fmaxf(var, 0.f) + p.ln_eps));
+        }
+#pragma unroll
+        for (int i = 0; i < NBLK; ++i) {
+          const int src = (i >> 1) * 16 + (lane & 15);
+          st[i] = make_float2(__shfl(mine[i & 1].x, src, 64), __shfl(mine[i & 1].y, src, 64));
         }
       }
     }
