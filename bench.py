@@ -117,10 +117,11 @@ def cpu_baseline(cfg, sd, budget_s=15.0, batch=8):
 
 def fc1_kernel_time(model, x, steps):
     """Average duration (ms) of the fc1 LN+GELU GEMM launches over `steps` forwards, by events on the launch
-    stream around each such launch."""
+    stream around each such launch.  An event pair with nothing between is recorded right behind each launch; its
+    average interval (what two records cost by themselves) is returned beside the raw average."""
     from vitm_amd import _ops
     orig = _ops.gemm
-    pairs = []
+    pairs, nulls = [], []
 
     def timed_gemm(A, pk, out, epilogue, M, **kw):
         if epilogue != _ops.EPI_LN_GELU:
@@ -130,6 +131,10 @@ def fc1_kernel_time(model, x, steps):
         r = orig(A, pk, out, epilogue, M, **kw)
         e1.record()
         pairs.append((e0, e1))
+        n0, n1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        n0.record()
+        n1.record()
+        nulls.append((n0, n1))
         return r
 
     _ops.gemm = timed_gemm
@@ -141,7 +146,8 @@ def fc1_kernel_time(model, x, steps):
     finally:
         _ops.gemm = orig
     ms = [a.elapsed_time(b) for a, b in pairs]
-    return sum(ms) / len(ms), len(ms)
+    null_ms = [a.elapsed_time(b) for a, b in nulls]
+    return sum(ms) / len(ms), len(ms), sum(null_ms) / len(null_ms)
 
 
 def train_bench(args, world, rank, dist, dev):
@@ -380,7 +386,7 @@ def main():
     if rank == 0:
         ms_step = elapsed / args.steps * 1e3
         value = world * args.batch * args.steps / elapsed
-        fc1_ms, n_launch = fc1_kernel_time(model, x, max(2, min(args.steps, 10)))
+        fc1_ms, n_launch, null_ms = fc1_kernel_time(model, x, max(2, min(args.steps, 10)))
         M, N, K = args.batch * shp["tokens"], shp["hidden"], shp["embed_dim"]
         fc1_tflops = 2.0 * M * N * K / (fc1_ms * 1e-3) / 1e12
         model_tflops = value / world * gflop_img / 1e3
@@ -402,7 +408,11 @@ def main():
                          "traffic": measured_traffic(args.config, args.batch),
                          "kernel": "gemm_pp_shared_kernel<EPI_LN_GELU> (fc1: LayerNorm-folded 256x256 ping-pong GEMM + GELU; whole tiles and the leftover-tile slices in one launch)",
                          "flops_per_launch": 2.0 * M * N * K, "avg_launch_ms": round(fc1_ms, 4),
-                         "launches_timed": n_launch},
+                         "launches_timed": n_launch,
+                         # what two event records cost with nothing between them, measured right behind each launch:
+                         # the part of avg_launch_ms that is not the kernel (achieved / frac do NOT subtract it)
+                         "event_pair_overhead_ms": round(null_ms, 4),
+                         "avg_launch_ms_net": round(fc1_ms - null_ms, 4)},
             "whole_forward": {"tflops_per_gpu": round(model_tflops, 1),
                               "frac_of_bf16_peak": round(model_tflops / PEAK_BF16_TFLOPS, 4)},
             "rounds": {"timed": len(rounds), "steps_each": args.steps, "reported": "median",
