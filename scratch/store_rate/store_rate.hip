@@ -8,7 +8,7 @@
 #include <algorithm>
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-template <bool NT>
+template <bool NT, int SEG>
 __global__ __launch_bounds__(512, 2) void k(char* dst, long long pitch, int tiles, long long tile_stride_wg, unsigned long long* out) {
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   // wave (g, c): rows 128 g .., columns 64 c ..; store s: rows 16 (s / 2) + 8 (s & 1) + (lane & 7), 8 lanes x 16 B per row
@@ -21,10 +21,17 @@ __global__ __launch_bounds__(512, 2) void k(char* dst, long long pitch, int tile
     char* tb = base + (long long)t * 256 * pitch;      // next 256 rows
     __syncthreads();
     t0 = __builtin_amdgcn_s_memtime();
+    constexpr int LPR = SEG / 16;          // lanes per row
+    constexpr int RPI = 64 / LPR;          // rows per instruction
+    // the workgroup's 8 waves tile the 256 x 512-byte output: wave w owns 512 / SEG column groups? keep it simple:
+    // wave w writes rows [w * 16 * RPI / 8 ...): 16 instructions x RPI rows, SEG bytes at column offset (w % (512 / SEG)) * SEG
+    constexpr int CG = 512 / SEG;          // column groups of SEG bytes in the tile's 512-byte rows
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
-      const int row = 128 * g + 16 * (s >> 1) + 8 * (s & 1) + (lane >> 3);
-      u32x4* p = (u32x4*)(tb + (long long)row * pitch + c * 128 + (lane & 7) * 16);
+      const int cgp = wave % CG;
+      const int rband = wave / CG;                         // 8 / CG row bands
+      const int row = (rband * 16 + s) * RPI + lane / LPR; // 16 * RPI rows per band
+      u32x4* p = (u32x4*)(tb + (long long)(row % 256) * pitch + cgp * SEG + (lane % LPR) * 16);
       if (NT) __builtin_nontemporal_store(v, p); else *p = v;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -41,20 +48,23 @@ int main() {
   char* dst; hipMalloc(&dst, per_wg * 256);
   hipMemset(dst, 0, per_wg * 256);
   unsigned long long* out; hipMalloc(&out, 256 * 8 * 8);
-  for (int nt = 1; nt >= 0; --nt)
-    for (int grid : {256, 128, 64, 32, 8, 1}) {
-      for (int rep = 0; rep < 3; ++rep) {
-        if (nt) hipLaunchKernelGGL(k<true>, dim3(grid), dim3(512), 0, 0, dst, pitch, tiles, per_wg, out);
-        else hipLaunchKernelGGL(k<false>, dim3(grid), dim3(512), 0, 0, dst, pitch, tiles, per_wg, out);
-      }
-      hipDeviceSynchronize();
-      std::vector<unsigned long long> h(256 * 8);
-      hipMemcpy(h.data(), out, h.size() * 8, hipMemcpyDeviceToHost);
-      std::vector<double> cyc;
-      for (int b = 0; b < grid; ++b) { unsigned long long m = 0; for (int w = 0; w < 8; ++w) m = std::max(m, h[b * 8 + w]); cyc.push_back((double)m / tiles); }
-      std::sort(cyc.begin(), cyc.end());
-      printf("%s grid %3d: %7.0f cycles per 128-KiB tile (median CU) = %5.1f B/clk/CU\n", nt ? "non-temporal" : "plain       ", grid,
-             cyc[grid / 2], 131072.0 / cyc[grid / 2]);
+  auto run = [&](int seg, int grid) {
+    for (int rep = 0; rep < 3; ++rep) {
+      if (seg == 64) hipLaunchKernelGGL((k<true, 64>), dim3(grid), dim3(512), 0, 0, dst, pitch, tiles, per_wg, out);
+      else if (seg == 128) hipLaunchKernelGGL((k<true, 128>), dim3(grid), dim3(512), 0, 0, dst, pitch, tiles, per_wg, out);
+      else if (seg == 256) hipLaunchKernelGGL((k<true, 256>), dim3(grid), dim3(512), 0, 0, dst, pitch, tiles, per_wg, out);
+      else hipLaunchKernelGGL((k<true, 512>), dim3(grid), dim3(512), 0, 0, dst, pitch, tiles, per_wg, out);
     }
+    (void)hipDeviceSynchronize();
+    std::vector<unsigned long long> h(256 * 8);
+    (void)hipMemcpy(h.data(), out, h.size() * 8, hipMemcpyDeviceToHost);
+    std::vector<double> cyc;
+    for (int b = 0; b < grid; ++b) { unsigned long long m = 0; for (int w = 0; w < 8; ++w) m = std::max(m, h[b * 8 + w]); cyc.push_back((double)m / tiles); }
+    std::sort(cyc.begin(), cyc.end());
+    printf("non-temporal, %4d contiguous bytes per row and instruction (%2d rows), grid %3d: %7.0f cycles per 128-KiB tile = %5.1f B/clk/CU\n",
+           seg, 1024 / seg, grid, cyc[grid / 2], 131072.0 / cyc[grid / 2]);
+  };
+  for (int seg : {64, 128, 256, 512})
+    for (int grid : {256, 32, 1}) run(seg, grid);
   return 0;
 }

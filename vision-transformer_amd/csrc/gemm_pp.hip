@@ -538,8 +538,14 @@ __device__ __forceinline__ void tile_loop(const GemmArgs& p, char* smem) {
     }
     const bool stores_on = (PP_ABLATE & 4) == 0;
     if (EPI != VITM_EPI_RESIDUAL && EPI != VITM_EPI_DGELU) {
+      // The two waves of a SIMD (one per wave group) run this epilogue side by side, and at equal priority the older
+      // one (group 0) wins every issue slot: it finishes ~5 k cycles before group 1 and then waits for it at the first
+      // barrier of the next tile.  Group 1 therefore goes first for three quarters of its blocks (per-wave stamps:
+      // fc1 launch -1.5 %)
+      if (grp == 1) __builtin_amdgcn_s_setprio(2);
 #pragma unroll
       for (int i = 0; i < NBLK; ++i) {
+        if (i == (3 * NBLK + 3) / 4 && grp == 1) __builtin_amdgcn_s_setprio(0);
         f32x2_t v[8];  // the 16 values of row i: pairs (j, half)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -582,6 +588,7 @@ __device__ __forceinline__ void tile_loop(const GemmArgs& p, char* smem) {
           }
         }
       }
+      if (grp == 1) __builtin_amdgcn_s_setprio(0);   // (NBLK < 2: the reset inside the loop did not run)
     } else {
       // residual: out = resid + (g * acc + c), one rounding.  The fp32 values are swapped (4 dwords per quad) so
       // the residual is read and the result written as 16 bytes per lane.  Two halves of 4 rows keep the
