@@ -608,18 +608,31 @@ __device__ __forceinline__ void tile_loop(const GemmArgs& p, char* smem) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) rs[i][0] = rs[i][1] = rq[i][0] = rq[i][1] = 0.f;
       }
+      // full tiles: residual and output through one advancing pointer each, no per-lane tests (see the bias branch)
+      const bool fast = !SLICE && stores_on && m0 + BM <= p.M && n0 + BN <= p.N;
+      const bf16_t* rfast = p.resid + (int64_t)mst * p.ldr + nst;
+      bf16_t* ofast = (bf16_t*)p.out + (int64_t)mst * p.ldo + nst;
 #pragma unroll
       for (int ih = 0; ih < IH; ++ih) {
         uint4 rres[I4][2];   // residual in store layout: [.][0] row (r&7), [.][1] row 8 + (r&7), columns nst .. +7
+        if (fast) {
 #pragma unroll
-        for (int i4 = 0; i4 < I4; ++i4)
-#pragma unroll
-          for (int h = 0; h < 2; ++h) {
-            int m = mst + 16 * (I4 * ih + i4) + 8 * h;
-            m = m < p.M ? m : p.M - 1;
-            const int n = nst < p.N ? nst : p.N - 8;
-            rres[i4][h] = *(const uint4*)(p.resid + (int64_t)m * p.ldr + n);
+          for (int i4 = 0; i4 < I4; ++i4) {
+            rres[i4][0] = *(const uint4*)rfast;
+            rres[i4][1] = *(const uint4*)(rfast + 8 * p.ldr);
+            rfast += 16 * p.ldr;
           }
+        } else {
+#pragma unroll
+          for (int i4 = 0; i4 < I4; ++i4)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              int m = mst + 16 * (I4 * ih + i4) + 8 * h;
+              m = m < p.M ? m : p.M - 1;
+              const int n = nst < p.N ? nst : p.N - 8;
+              rres[i4][h] = *(const uint4*)(p.resid + (int64_t)m * p.ldr + n);
+            }
+        }
 #pragma unroll
         for (int i4 = 0; i4 < I4; ++i4) {
           const int i = I4 * ih + i4;
@@ -688,9 +701,12 @@ __device__ __forceinline__ void tile_loop(const GemmArgs& p, char* smem) {
               }
             }
             const int m = mst + 16 * i + 8 * h;
-            if (stores_on && m < p.M && nst < p.N && (!SLICE || (i0 + i >= is0 && i0 + i < is1)))
+            if (fast)
+              store_out(ofast + (h ? 8 * p.ldo : 0), o.x, o.y, o.z, o.w);
+            else if (stores_on && m < p.M && nst < p.N && (!SLICE || (i0 + i >= is0 && i0 + i < is1)))
               store_out((bf16_t*)p.out + (int64_t)m * p.ldo + nst, o.x, o.y, o.z, o.w);
           }
+          ofast += 16 * p.ldo;
         }
       }
       if (STATS) {
