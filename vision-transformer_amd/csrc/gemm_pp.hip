@@ -546,7 +546,17 @@ __device__ __forceinline__ void tile_loop(const GemmArgs& p, char* smem) {
       // a tile with no ragged edge stores without per-lane tests, from one pointer advanced by 16 rows per block (the
       // general path costs every block ~14 VALU instructions of address arithmetic and compares and four branches)
       const bool fast = !SLICE && stores_on && m0 + BM <= p.M && n0 + BN <= p.N && (!IM2COL || p.cls == 0);
-      bf16_t* ofast = (bf16_t*)p.out + (int64_t)mst * p.ldo + nst;
+      // The exchanges above leave lane l with row (l & 7) and 16-byte chunk CH(l >> 3) of the wave's 128-byte rows.  Stored
+      // like that, the 8 lanes of a row are 8 lanes apart, and the memory path takes 3.5 x as long over the instruction as
+      // when consecutive lanes write consecutive chunks (8.7 k against 2.5 k cycles per 128-KiB tile on a CU by itself).
+      // Full tiles therefore turn the 8 x 8 lane grid round first (4 cross-lane reads per store): lane l ends up with row
+      // l >> 3, chunk l & 7.
+      // Not where the GELU keeps the VALU busier than the stores keep the memory path (the stores hide behind it).
+      constexpr bool TURN = EPI == VITM_EPI_BIAS || EPI == VITM_EPI_LN;
+      const int xsrc = 4 * ((lane >> 3) + 8 * ((lane & 7) >> 2) + 16 * (((lane & 1) << 1) | ((lane >> 1) & 1)));
+      bf16_t* ofast = TURN ? (bf16_t*)p.out + (int64_t)(m0 + grp * 128 + i0 * 16 + (lane >> 3)) * p.ldo + (n0 + wc * 64 + 8 * (lane & 7))
+                           : (bf16_t*)p.out + (int64_t)mst * p.ldo + nst;
+      auto turn = [&](unsigned x) { return TURN ? (unsigned)__builtin_amdgcn_ds_bpermute(xsrc, (int)x) : x; };
 #pragma unroll
       for (int i = 0; i < NBLK; ++i) {
         if (i == (3 * NBLK + 3) / 4 && grp == 1) __builtin_amdgcn_s_setprio(0);
@@ -580,8 +590,8 @@ __device__ __forceinline__ void tile_loop(const GemmArgs& p, char* smem) {
         rowpair_exchange1(c0, c1, hi8);
         rowpair_exchange1(d0, d1, hi8);
         if (fast) {
-          store_out(ofast, a0, b0, c0, d0);
-          store_out(ofast + 8 * p.ldo, a1, b1, c1, d1);
+          store_out(ofast, turn(a0), turn(b0), turn(c0), turn(d0));
+          store_out(ofast + 8 * p.ldo, turn(a1), turn(b1), turn(c1), turn(d1));
           ofast += 16 * p.ldo;
         } else if (stores_on && nst < p.N && (!SLICE || (i0 + i >= is0 && i0 + i < is1))) {
           const int m1 = mst + 16 * i, m2 = m1 + 8;
@@ -610,16 +620,27 @@ __device__ __forceinline__ void tile_loop(const GemmArgs& p, char* smem) {
       }
       // full tiles: residual and output through one advancing pointer each, no per-lane tests (see the bias branch)
       const bool fast = !SLICE && stores_on && m0 + BM <= p.M && n0 + BN <= p.N;
-      const bf16_t* rfast = p.resid + (int64_t)mst * p.ldr + nst;
-      bf16_t* ofast = (bf16_t*)p.out + (int64_t)mst * p.ldo + nst;
+      // Full tiles read the residual and write the output with consecutive lanes on consecutive 16-byte chunks of a row
+      // (lane l: row l >> 3, chunk l & 7) and turn the lane grid to and from the layout the arithmetic runs in (row l & 7,
+      // chunk CH(l >> 3)) with 4 cross-lane reads per 1-KiB access: see the bias branch
+      constexpr bool TURN = EPI == VITM_EPI_RESIDUAL;
+      const int xsrc = 4 * ((lane >> 3) + 8 * ((lane & 7) >> 2) + 16 * (((lane & 1) << 1) | ((lane >> 1) & 1)));   // row-major <- compute
+      const int isrc = 4 * (8 * (lane & 7) + ((((lane >> 4) & 1) << 1) | ((lane >> 5) & 1)) + 4 * ((lane >> 3) & 1));   // compute <- row-major
+      auto turn_out = [&](unsigned x) { return TURN ? (unsigned)__builtin_amdgcn_ds_bpermute(xsrc, (int)x) : x; };
+      auto turn_in = [&](unsigned x) { return TURN ? (unsigned)__builtin_amdgcn_ds_bpermute(isrc, (int)x) : x; };
+      const int64_t rowf = TURN ? m0 + grp * 128 + i0 * 16 + (lane >> 3) : mst;
+      const int colf = TURN ? n0 + wc * 64 + 8 * (lane & 7) : nst;
+      const bf16_t* rfast = p.resid + rowf * p.ldr + colf;
+      bf16_t* ofast = (bf16_t*)p.out + rowf * p.ldo + colf;
 #pragma unroll
       for (int ih = 0; ih < IH; ++ih) {
         uint4 rres[I4][2];   // residual in store layout: [.][0] row (r&7), [.][1] row 8 + (r&7), columns nst .. +7
         if (fast) {
 #pragma unroll
           for (int i4 = 0; i4 < I4; ++i4) {
-            rres[i4][0] = *(const uint4*)rfast;
-            rres[i4][1] = *(const uint4*)(rfast + 8 * p.ldr);
+            const uint4 r0 = *(const uint4*)rfast, r1 = *(const uint4*)(rfast + 8 * p.ldr);
+            rres[i4][0] = make_uint4(turn_in(r0.x), turn_in(r0.y), turn_in(r0.z), turn_in(r0.w));
+            rres[i4][1] = make_uint4(turn_in(r1.x), turn_in(r1.y), turn_in(r1.z), turn_in(r1.w));
             rfast += 16 * p.ldr;
           }
         } else {
@@ -702,7 +723,7 @@ __device__ __forceinline__ void tile_loop(const GemmArgs& p, char* smem) {
             }
             const int m = mst + 16 * i + 8 * h;
             if (fast)
-              store_out(ofast + (h ? 8 * p.ldo : 0), o.x, o.y, o.z, o.w);
+              store_out(ofast + (h ? 8 * p.ldo : 0), turn_out(o.x), turn_out(o.y), turn_out(o.z), turn_out(o.w));
             else if (stores_on && m < p.M && nst < p.N && (!SLICE || (i0 + i >= is0 && i0 + i < is1)))
               store_out((bf16_t*)p.out + (int64_t)m * p.ldo + nst, o.x, o.y, o.z, o.w);
           }
