@@ -620,27 +620,18 @@ __device__ __forceinline__ void tile_loop(const GemmArgs& p, char* smem) {
       }
       // full tiles: residual and output through one advancing pointer each, no per-lane tests (see the bias branch)
       const bool fast = !SLICE && stores_on && m0 + BM <= p.M && n0 + BN <= p.N;
-      // Full tiles read the residual and write the output with consecutive lanes on consecutive 16-byte chunks of a row
-      // (lane l: row l >> 3, chunk l & 7) and turn the lane grid to and from the layout the arithmetic runs in (row l & 7,
-      // chunk CH(l >> 3)) with 4 cross-lane reads per 1-KiB access: see the bias branch
-      constexpr bool TURN = EPI == VITM_EPI_RESIDUAL;
-      const int xsrc = 4 * ((lane >> 3) + 8 * ((lane & 7) >> 2) + 16 * (((lane & 1) << 1) | ((lane >> 1) & 1)));   // row-major <- compute
-      const int isrc = 4 * (8 * (lane & 7) + ((((lane >> 4) & 1) << 1) | ((lane >> 5) & 1)) + 4 * ((lane >> 3) & 1));   // compute <- row-major
-      auto turn_out = [&](unsigned x) { return TURN ? (unsigned)__builtin_amdgcn_ds_bpermute(xsrc, (int)x) : x; };
-      auto turn_in = [&](unsigned x) { return TURN ? (unsigned)__builtin_amdgcn_ds_bpermute(isrc, (int)x) : x; };
-      const int64_t rowf = TURN ? m0 + grp * 128 + i0 * 16 + (lane >> 3) : mst;
-      const int colf = TURN ? n0 + wc * 64 + 8 * (lane & 7) : nst;
-      const bf16_t* rfast = p.resid + rowf * p.ldr + colf;
-      bf16_t* ofast = (bf16_t*)p.out + rowf * p.ldo + colf;
+      // (no lane-grid turn here: with the residual read and the output written, the 8 cross-lane reads per 16-row block
+      // cost more than the faster stores return: proj +3.6 %, fc2 +1.9 % in the kernel trace, A/B of the whole forward)
+      const bf16_t* rfast = p.resid + (int64_t)mst * p.ldr + nst;
+      bf16_t* ofast = (bf16_t*)p.out + (int64_t)mst * p.ldo + nst;
 #pragma unroll
       for (int ih = 0; ih < IH; ++ih) {
         uint4 rres[I4][2];   // residual in store layout: [.][0] row (r&7), [.][1] row 8 + (r&7), columns nst .. +7
         if (fast) {
 #pragma unroll
           for (int i4 = 0; i4 < I4; ++i4) {
-            const uint4 r0 = *(const uint4*)rfast, r1 = *(const uint4*)(rfast + 8 * p.ldr);
-            rres[i4][0] = make_uint4(turn_in(r0.x), turn_in(r0.y), turn_in(r0.z), turn_in(r0.w));
-            rres[i4][1] = make_uint4(turn_in(r1.x), turn_in(r1.y), turn_in(r1.z), turn_in(r1.w));
+            rres[i4][0] = *(const uint4*)rfast;
+            rres[i4][1] = *(const uint4*)(rfast + 8 * p.ldr);
             rfast += 16 * p.ldr;
           }
         } else {
@@ -723,7 +714,7 @@ __device__ __forceinline__ void tile_loop(const GemmArgs& p, char* smem) {
             }
             const int m = mst + 16 * i + 8 * h;
             if (fast)
-              store_out(ofast + (h ? 8 * p.ldo : 0), turn_out(o.x), turn_out(o.y), turn_out(o.z), turn_out(o.w));
+              store_out(ofast + (h ? 8 * p.ldo : 0), o.x, o.y, o.z, o.w);
             else if (stores_on && m < p.M && nst < p.N && (!SLICE || (i0 + i >= is0 && i0 + i < is1)))
               store_out((bf16_t*)p.out + (int64_t)m * p.ldo + nst, o.x, o.y, o.z, o.w);
           }
