@@ -357,6 +357,8 @@ int vitm_cross_entropy_f32(const float* logits, int64_t ld, const int64_t* label
  * (16384) -- a larger B is refused with VITM_EINVAL.  The call allocates and frees nothing.  The first call on a
  * device looks the array's address up (hipGetSymbolAddress): make that call outside a graph capture.  All calls on one
  * GPU share the array: calls that overlap on one GPU (different streams) race; calls on one stream are ordered.
+ * `stream` must belong to the calling thread's current device (each GPU has its own copy of the array and the kernels
+ * must get the copy of the GPU they run on): a stream of another device is refused with VITM_EINVAL.
  */
 int vitm_cross_entropy_f32_noalloc(const float* logits, int64_t ld, const int64_t* labels, int B, int C, float* loss,
                                    float* dlogits, int64_t lddl, vitm_stream_t stream);

@@ -62,7 +62,8 @@ def run_reference(model, x: torch.Tensor):
     return stages, emb, logits
 
 
-def gen(name: str, batch: int, seed: int, depth=None, keep_stages=True, emb_rows=None):
+def gen(name: str, batch: int, seed: int, depth=None, keep_stages=True, emb_rows=None, tag=None):
+    """``tag``: file name stem when it differs from the configuration name (a cut-depth variant)."""
     cfg = W.CONFIGS[name]
     sd = W.make_state_dict(cfg, seed, depth)
     model = build_reference(cfg, depth)
@@ -85,7 +86,7 @@ def gen(name: str, batch: int, seed: int, depth=None, keep_stages=True, emb_rows
         out["features"] = stages[0].numpy()
         for i, s in enumerate(stages[1:]):
             out[f"block{i}"] = s.numpy()
-    path = os.path.join(HERE, f"{name}.npz")
+    path = os.path.join(HERE, f"{tag or name}.npz")
     np.savez_compressed(path, **out)
     print(f"{name}: wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB), "
           f"max|logit|={logits.abs().max():.3f}, reference bf16-vs-fp32 logit err "

@@ -98,7 +98,7 @@ def test_flat_gradient_allreduce_two_ranks():
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 2000) + 7
+    port = _free_port()
     procs = [ctx.Process(target=_allreduce_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
@@ -149,7 +149,7 @@ def test_bucketed_gradient_allreduce_two_ranks():
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 2000) + 11
+    port = _free_port()
     procs = [ctx.Process(target=_reducer_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()

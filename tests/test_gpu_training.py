@@ -218,6 +218,51 @@ def test_vit_l16_bf16_training_step_tracks_float64(monkeypatch):
     assert 0 < moved <= 2e-5      # first step: lr = 0.01 * 1e-3, AdamW update of unit size
 
 
+def test_vit_l16_bf16_training_step_full_size_route(monkeypatch):
+    """Benchmark configuration 5 at the size it is benchmarked: ViT-L/16 shapes, batch 128 (M = 25 216 rows: the
+    256x256-tile GEMMs with carried moments in the forward, the multi-slice weight-gradient GEMM, the persistent
+    attention kernels), depth 2.  The batch is the 4-image float64 case of the test above repeated 32 times: in exact
+    arithmetic the mean loss and every mean gradient equal those of the 4 images, so the float64 autograd of the oracle
+    on 4 images is the reference for the whole batch, at the bf16 bars of this file.  Two steps from one state are
+    bit-identical (every reduction has a fixed order)."""
+    import copy
+    from oracle import vit_oracle as O
+    from vitm_amd import training
+    cfg = dict(W.CONFIGS["vit_l16"], depth=2)
+    model = _model(cfg, 31).cpu()
+    sd64 = {k: v.detach().double().requires_grad_(True) for k, v in model.state_dict().items()}
+    x4 = torch.from_numpy(W.make_input(cfg, 4, 32)).to(torch.bfloat16)
+    y4 = torch.tensor([5, 999, 0, 417])
+    monkeypatch.setattr(O, "_t", lambda sd, key, dtype: None if sd.get(key) is None else sd[key].to(dtype))
+    loss64 = torch.nn.functional.cross_entropy(O.vitc_forward(x4.double(), sd64, W.oracle_cfg(cfg), dtype=torch.float64), y4)
+    loss64.backward()
+    norm64 = torch.sqrt(sum((v.grad ** 2).sum() for v in sd64.values() if v.grad is not None)).item()
+    x, y = x4.repeat(32, 1, 1, 1).cuda(), y4.repeat(32).cuda()
+    model = model.cuda()
+    state = copy.deepcopy(model.state_dict())
+    results = []
+    for _ in range(2):
+        model.load_state_dict(state)
+        opt, sched = training.reference_optimizer_and_scheduler(model, 1000)
+        tr = training.Trainer(model, opt, sched, max_norm=1.0, compute_dtype=torch.bfloat16)
+        loss = tr.step(x, y)
+        results.append((loss.clone(), tr.last_grad_norm.clone(), {k: p.detach().clone() for k, p in model.named_parameters()}))
+    (l0, n0, p0), (l1, n1, p1) = results
+    assert torch.equal(l0, l1) and torch.equal(n0, n1), "two steps from one state: loss / gradient norm differ"
+    for k in p0:
+        assert torch.equal(p0[k], p1[k]), f"{k}: parameters after the step differ between two runs"
+    assert abs(l0.item() - loss64.item()) <= 1e-2 * abs(loss64.item()), (l0.item(), loss64.item())
+    assert abs(n0.item() - norm64) <= 3e-2 * norm64, (n0.item(), norm64)
+    # the gradients themselves, through the autograd interface on the same batch
+    model.load_state_dict(state)
+    tr.grads.zero()
+    loss = training.CrossEntropyLoss()(model(x), y)
+    loss.backward()
+    for k, p in model.named_parameters():
+        c = _cos(p.grad.cpu(), sd64[k].grad)
+        assert c >= (0.99 if p.numel() >= 1000 else 0.95), f"{k}: {c:.4f}"
+
+
 # ---- flat parameters / single-launch AdamW -------------------------------------------------------------------------
 def _batch(cfg, batch, seed):
     x = torch.from_numpy(W.make_input(cfg, batch, seed)).cuda()

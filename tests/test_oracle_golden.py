@@ -23,9 +23,12 @@ def _rel(a, b):
     return np.abs(a - b).max() / max(np.abs(b).max(), 1e-12)
 
 
+FIXTURE_CONFIG = {"vit_l16_d4": "vit_l16"}   # fixtures of a cut-depth network: file stem -> configuration
+
+
 def _load(name):
     g = np.load(os.path.join(GOLD, f"{name}.npz"))
-    cfg = W.CONFIGS[name]
+    cfg = W.CONFIGS[FIXTURE_CONFIG.get(name, name)]
     depth = int(g["depth"])
     sd = {k: torch.from_numpy(v) for k, v in W.make_state_dict(cfg, int(g["seed"]), depth).items()}
     x = torch.from_numpy(W.make_input(cfg, int(g["batch"]), int(g["seed"]) + 1))
@@ -45,10 +48,10 @@ def test_oracle_stages_match_reference(name):
     assert _rel(logits.numpy(), g["logits"]) < TOL
 
 
-@pytest.mark.parametrize("name", ["vit_tiny_cifar", "vit_s16", "vit_b16"])
+@pytest.mark.parametrize("name", ["vit_tiny_cifar", "vit_s16", "vit_b16", "vit_b16_384", "vit_l16_d4"])
 def test_oracle_logits_match_reference(name):
     g, cfg, sd, x = _load(name)
-    logits, emb = O.vitc_forward(x, sd, W.oracle_cfg(cfg), return_embeddings=True)
+    logits, emb = O.vitc_forward(x, sd, dict(W.oracle_cfg(cfg), depth=int(g["depth"])), return_embeddings=True)
     assert logits.shape == (int(g["batch"]), cfg["num_classes"])
     assert _rel(logits.numpy(), g["logits"]) < TOL
     if "embeddings_rows" in g:

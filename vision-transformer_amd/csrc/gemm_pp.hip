@@ -760,9 +760,14 @@ __device__ __forceinline__ void tile_loop(const GemmArgs& p, char* smem) {
           const float4 u = *(const float4*)(sb + tid * 32), w = *(const float4*)(sb + tid * 32 + 16);
           const int R = tid & 127, ib = R >> 4;
           const int m = m0 + (tid >> 7) * 128 + i0 * 16 + R;
-          if (ib < NBLK && m < p.M && (!SLICE || (i0 + ib >= is0 && i0 + ib < is1)))
-            *(float2*)(p.stats_out + ((int64_t)m * VITM_STATS_PARTS + nt_) * 2) =
-                make_float2((u.x + u.z) + (w.x + w.z), (u.y + u.w) + (w.y + w.w));
+          if (ib < NBLK && m < p.M && (!SLICE || (i0 + ib >= is0 && i0 + ib < is1))) {
+            float2* so = (float2*)(p.stats_out + ((int64_t)m * VITM_STATS_PARTS + nt_) * 2);
+            *so = make_float2((u.x + u.z) + (w.x + w.z), (u.y + u.w) + (w.y + w.w));
+            // the last column tile also clears the slots of the column tiles this shape does not have: the consumer adds
+            // all VITM_STATS_PARTS slots, and the buffer then needs no clearing by whoever allocated it
+            if (nt_ == p.tilesN - 1)
+              for (int z = nt_ + 1; z < VITM_STATS_PARTS; ++z) so[z - nt_] = make_float2(0.f, 0.f);
+          }
         }
       }
     }

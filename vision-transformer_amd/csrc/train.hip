@@ -755,13 +755,26 @@ extern "C" int vitm_cross_entropy_f32(const float* logits, int64_t ld, const int
 constexpr int CE_NOALLOC_MAX_ROWS = 16384;
 static __device__ __align__(256) float scratch[CE_NOALLOC_MAX_ROWS];
 
-static int scratch_on_current_device(float** out) {
+static int scratch_on_current_device(hipStream_t st, float** out) {
   constexpr int MAXDEV = 64;
   static std::atomic<float*> ptrs[MAXDEV];
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAXDEV) {
     vitm_set_error("vitm_cross_entropy_f32_noalloc: cannot identify the current device");
     return VITM_ELAUNCH;
+  }
+  // the kernels run on the stream's GPU and must get THAT GPU's copy of the array: a stream of another device than
+  // the calling thread's current one is refused (the null stream belongs to the current device)
+  hipDevice_t sdev = dev;
+  if (st != nullptr && hipStreamGetDevice(st, &sdev) != hipSuccess) {
+    (void)hipGetLastError();
+    vitm_set_error("vitm_cross_entropy_f32_noalloc: cannot identify the stream's device");
+    return VITM_ELAUNCH;
+  }
+  if ((int)sdev != dev) {
+    vitm_set_error("vitm_cross_entropy_f32_noalloc: the stream belongs to device %d but the current device is %d "
+                   "(make the stream's device current before the call)", (int)sdev, dev);
+    return VITM_EINVAL;
   }
   float* p = ptrs[dev].load(std::memory_order_acquire);
   if (p == nullptr) {
@@ -786,9 +799,9 @@ extern "C" int vitm_cross_entropy_f32_noalloc(const float* logits, int64_t ld, c
   VITM_REQUIRE(B <= CE_NOALLOC_MAX_ROWS, "vitm_cross_entropy_f32_noalloc: B=%d exceeds the built-in scratch of %d rows "
                "(use vitm_cross_entropy_f32 with a caller-supplied row_loss buffer)", B, CE_NOALLOC_MAX_ROWS);
   float* row_loss = nullptr;
-  const int rc = scratch_on_current_device(&row_loss);
-  if (rc != VITM_OK) return rc;
   hipStream_t st = (hipStream_t)stream;
+  const int rc = scratch_on_current_device(st, &row_loss);
+  if (rc != VITM_OK) return rc;
   // rows 0 .. B-1 of the array are rewritten in full by every call: nothing has to start at zero
   hipLaunchKernelGGL(cross_entropy_rows_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, st, logits, ld, labels, B, C, row_loss, dlogits, lddl);
   hipLaunchKernelGGL(cross_entropy_mean_kernel, dim3(1), dim3(64), 0, st, (const float*)row_loss, B, loss);

@@ -149,25 +149,12 @@ def uses_big_tile(M: int, pk: "PackedLinear") -> bool:
 
 
 def new_carried_stats(M: int, device) -> torch.Tensor:
-    """Zeroed [M, VITM_STATS_PARTS, 2] buffer for the LayerNorm moments that vitm_gemm_stats carries between GEMMs."""
-    return torch.zeros((M, _lib.STATS_PARTS, 2), dtype=torch.float32, device=device)
-
-
-_carried_cache = {}
-
-
-def carried_stats(M: int, width: int, device) -> torch.Tensor:
-    """The carried-moments buffer for rows M of a stream `width` columns wide, kept between forwards: the producing
-    epilogues rewrite the slots of their column tiles in full and never touch the others, which therefore stay zero, so
-    nothing has to be cleared per call.  One buffer per (device, M, column tiles): forwards that overlap on one device
-    (several streams) must not share it -- use new_carried_stats() for those."""
-    key = (torch.device(device).index, M, (width + 255) // 256)
-    buf = _carried_cache.get(key)
-    if buf is None:
-        if len(_carried_cache) >= 8:
-            _carried_cache.clear()
-        buf = _carried_cache[key] = new_carried_stats(M, device)
-    return buf
+    """[M, VITM_STATS_PARTS, 2] buffer for the LayerNorm moments that vitm_gemm_stats carries between GEMMs.  It is
+    part of a forward's own workspace (never shared between forwards, so graph replays and forwards on several
+    streams cannot meet in it) and needs no clearing: the producing epilogue writes the slots of its column tiles
+    and zero-fills the slots of the column tiles the shape does not have, and a consumer only ever reads what a
+    producer of the same forward wrote."""
+    return torch.empty((M, _lib.STATS_PARTS, 2), dtype=torch.float32, device=device)
 
 
 def gemm(A: torch.Tensor, pk: PackedLinear, out: torch.Tensor, epilogue: int, M: int,

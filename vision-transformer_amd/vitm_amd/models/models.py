@@ -307,7 +307,7 @@ class Block(nn.Module):
                 carry = memo[M] = all(_ops.uses_big_tile(M, pk) for pk in
                                       (proj_pk, fc2_pk, attn._qkv_pack(dt, ln1), mlp._fc1_pack(dt, ln2)))
         if carry and "carried" not in ws:
-            ws["carried"] = _ops.carried_stats(M, D, x2d.device)
+            ws["carried"] = _ops.new_carried_stats(M, x2d.device)
             ws["carried_valid"] = False
         # attention branch
         if ln1 is None:

@@ -23,12 +23,12 @@ def layernorm_params(mod: nn.Module, what: str):
     if isinstance(mod, nn.LayerNorm) and len(mod.normalized_shape) == 1:
         if mod.elementwise_affine and mod.bias is not None:
             return mod.weight, mod.bias, mod.eps
-        # no affine (or no bias): unit weight / zero bias stand in, kept on the module, on the device of `like`
-        like = mod.weight if mod.weight is not None else None
-        dev = like.device if like is not None else getattr(mod, "_vitm_device", None)
+        # no affine (or no bias): unit weight / zero bias stand in, kept on the module.  They live where the weight lives
+        # or, for a module without parameters, on the current device (the callers run under torch.cuda.device(x.device)),
+        # and are rebuilt when that changes (model.to(another GPU))
+        dev = mod.weight.device if mod.weight is not None else torch.device("cuda", torch.cuda.current_device())
         unit = getattr(mod, "_vitm_unit", None)
-        if unit is None or (dev is not None and unit[0].device != dev):
-            dev = dev if dev is not None else torch.device("cuda", torch.cuda.current_device())
+        if unit is None or unit[0].device != dev:
             unit = (torch.ones(mod.normalized_shape[0], device=dev), torch.zeros(mod.normalized_shape[0], device=dev))
             object.__setattr__(mod, "_vitm_unit", unit)
         return (mod.weight if mod.weight is not None else unit[0]), unit[1], mod.eps
