@@ -1,0 +1,217 @@
+"""Run-to-run bit identity of every kernel family on a real MI355X, at grid sizes that put several workgroups on a CU.
+
+No kernel of the library uses atomics or an order that depends on timing, so the same launch on the same operands must
+return the same bits every time; a difference is a race or an instruction hazard, however small the numerical error.
+The case that led to this file: the 128x128-tile GEMM with a LayerNorm epilogue at M = 6304, N = 1152, K = 384 (a
+32-image shard of ViT-S/16: 450 workgroups, two per CU) wrote c[n] instead of rstd * (acc - mean * s[n]) + c[n] into a
+few hundred elements per launch -- rows 3, 7, 11, 15 of a tile, one column in eight -- and passed every tolerance test
+at the shapes the fixtures use.  Each case also checks the first result against plain fp32 arithmetic.
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+REPS = 12
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from vitm_amd import _ops
+    return _ops
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(DEV)
+
+
+def _repeat(launch, ref=None, rel=1.5e-2, reps=REPS, what=""):
+    """launch() -> fresh output tensor(s); all repetitions bitwise equal, the first one close to ``ref``."""
+    first = launch()
+    torch.cuda.synchronize()
+    first = first if isinstance(first, (tuple, list)) else (first,)
+    assert all(torch.isfinite(t.float()).all() for t in first), f"{what}: non-finite output"
+    if ref is not None:
+        err = (first[0].float() - ref).abs().max().item()
+        scale = ref.abs().max().item()
+        assert err <= rel * scale, f"{what}: max err {err:.4g} vs scale {scale:.4g}"
+    for it in range(1, reps):
+        again = launch()
+        again = again if isinstance(again, (tuple, list)) else (again,)
+        for a, b in zip(first, again):
+            if not torch.equal(a, b):
+                d = (a.float() - b.float()).abs()
+                bad = (d > 0).nonzero()
+                raise AssertionError(f"{what}: repetition {it} differs from the first in {bad.shape[0]} elements "
+                                     f"(max {d.max().item():.4g}); first at {bad[0].tolist()}")
+
+
+SMALL_TILE = [(6304, 1152, 384), (6304, 768, 384), (4728, 1152, 768), (6304, 384, 1536), (5910, 1280, 384)]
+
+
+@pytest.mark.parametrize("epi", ["ln", "ln_gelu", "ln_f32", "bias", "bias_gelu", "resid"])
+@pytest.mark.parametrize("M,N,K", SMALL_TILE)
+def test_gemm_small_tile_is_repeatable(ops, M, N, K, epi):
+    """The 128x128-tile kernel with 150-500 workgroups (one round of the chip, two workgroups per CU), every epilogue."""
+    A = (_rand(M, K, seed=1) * 1.2 + 0.1).to(torch.bfloat16)
+    W, b = _rand(N, K, seed=2, scale=K ** -0.5), _rand(N, seed=3, scale=0.5)
+    if epi.startswith("ln"):
+        lw, lb = 1.0 + 0.1 * _rand(K, seed=4), 0.1 * _rand(K, seed=5)
+        pk = ops.pack_linear(W, b, lw, lb)
+        stats = ops.ln_stats(A, M, K, 1e-5)
+        ref = F.layer_norm(A.float(), (K,), lw, lb, 1e-5) @ W.t() + b
+        code = ops.EPI_LN_GELU if epi == "ln_gelu" else ops.EPI_LN
+        if epi == "ln_gelu":
+            ref = F.gelu(ref)
+        dt = torch.float32 if epi == "ln_f32" else torch.bfloat16
+
+        def launch():
+            out = torch.full((M, N), float("nan"), dtype=dt, device=DEV)
+            return ops.gemm(A, pk, out, code, M, stats=stats)
+    elif epi == "resid":
+        gamma = 1.0 + 0.1 * _rand(N, seed=6)
+        x0 = _rand(M, N, seed=7).to(torch.bfloat16)
+        pk = ops.pack_linear(W, b, out_scale=gamma)
+        ref = x0.float() + gamma * (A.float() @ W.to(torch.bfloat16).float().t() + b)
+
+        def launch():
+            x = x0.clone()
+            return ops.gemm(A, pk, x, ops.EPI_RESIDUAL, M, resid=x)
+    else:
+        pk = ops.pack_linear(W, b)
+        ref = A.float() @ W.to(torch.bfloat16).float().t() + b
+        code = ops.EPI_BIAS_GELU if epi == "bias_gelu" else ops.EPI_BIAS
+        if epi == "bias_gelu":
+            ref = F.gelu(ref)
+
+        def launch():
+            out = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+            return ops.gemm(A, pk, out, code, M)
+    if epi != "ln_f32":   # an fp32 result never takes the big-tile route
+        assert not ops.uses_big_tile(M, pk), "shape meant for the 128x128-tile kernel"
+    _repeat(launch, ref, what=f"128x128 {epi} {M}x{N}x{K}")
+
+
+@pytest.mark.parametrize("epi", ["ln", "ln_gelu", "bias", "resid_stats"])
+@pytest.mark.parametrize("M,N,K", [(9000, 1152, 384), (12608, 2304, 768), (16400, 1536, 384), (50432, 768, 768)])
+def test_gemm_big_tile_is_repeatable(ops, M, N, K, epi):
+    """The persistent 256x256-tile kernel, shared leftover tiles and carried moments included."""
+    A = (_rand(M, K, seed=11) * 1.2 + 0.1).to(torch.bfloat16)
+    W, b = _rand(N, K, seed=12, scale=K ** -0.5), _rand(N, seed=13, scale=0.5)
+    if epi.startswith("ln"):
+        lw, lb = 1.0 + 0.1 * _rand(K, seed=14), 0.1 * _rand(K, seed=15)
+        pk = ops.pack_linear(W, b, lw, lb)
+        stats = ops.ln_stats(A, M, K, 1e-5)
+        ref = F.layer_norm(A.float(), (K,), lw, lb, 1e-5) @ W.t() + b
+        code = ops.EPI_LN_GELU if epi == "ln_gelu" else ops.EPI_LN
+        if epi == "ln_gelu":
+            ref = F.gelu(ref)
+
+        def launch():
+            out = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+            return ops.gemm(A, pk, out, code, M, stats=stats)
+    elif epi == "resid_stats":
+        if N > 1024:
+            pytest.skip("carried moments cover at most four column tiles")
+        gamma = 1.0 + 0.1 * _rand(N, seed=16)
+        x0 = _rand(M, N, seed=17).to(torch.bfloat16)
+        pk = ops.pack_linear(W, b, out_scale=gamma)
+        ref = x0.float() + gamma * (A.float() @ W.to(torch.bfloat16).float().t() + b)
+
+        def launch():
+            x = x0.clone()
+            carried = ops.new_carried_stats(M, DEV)
+            ops.gemm(A, pk, x, ops.EPI_RESIDUAL, M, resid=x, stats_out=carried)
+            return x, carried
+    else:
+        pk = ops.pack_linear(W, b)
+        ref = A.float() @ W.to(torch.bfloat16).float().t() + b
+
+        def launch():
+            out = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+            return ops.gemm(A, pk, out, ops.EPI_BIAS, M)
+    assert ops.uses_big_tile(M, pk), "shape meant for the 256x256-tile kernel"
+    _repeat(launch, ref, reps=8, what=f"256x256 {epi} {M}x{N}x{K}")
+
+
+@pytest.mark.parametrize("M,N,K,gelu", [(6304, 1152, 384, False), (3152, 1536, 384, True), (1576, 768, 768, False)])
+def test_gemm_f32_is_repeatable(ops, M, N, K, gelu):
+    A = _rand(M, K, seed=21)
+    W, b = _rand(N, K, seed=22, scale=K ** -0.5), _rand(N, seed=23, scale=0.5)
+    pk = ops.pack_linear(W, b, dtype=torch.float32)
+    ref = A @ W.t() + b
+    if gelu:
+        ref = F.gelu(ref)
+
+    def launch():
+        out = torch.full((M, N), float("nan"), dtype=torch.float32, device=DEV)
+        return ops.gemm(A, pk, out, ops.EPI_BIAS_GELU if gelu else ops.EPI_BIAS, M)
+    _repeat(launch, ref, rel=1e-4, reps=8, what=f"fp32 gemm {M}x{N}x{K}")
+
+
+@pytest.mark.parametrize("B,N,H,hd,dtype", [(32, 197, 6, 64, torch.bfloat16), (64, 197, 12, 64, torch.bfloat16),
+                                            (8, 577, 12, 64, torch.bfloat16), (64, 65, 8, 96, torch.bfloat16),
+                                            (32, 65, 3, 64, torch.bfloat16), (8, 197, 6, 64, torch.float32)])
+def test_attention_is_repeatable(ops, B, N, H, hd, dtype):
+    D = H * hd
+    qkv = _rand(B * N, 3 * D, seed=31).to(dtype)
+    q, k, v = qkv.float().reshape(B, N, 3, H, hd).permute(2, 0, 3, 1, 4)
+    ref = (torch.softmax(q @ k.transpose(-1, -2) * hd ** -0.5, -1) @ v).transpose(1, 2).reshape(B * N, D)
+
+    def launch():
+        out = torch.full((B * N, D), float("nan"), dtype=dtype, device=DEV)
+        ops.attention(qkv, out, B, N, H, hd, hd ** -0.5)
+        return out
+    _repeat(launch, ref, rel=2e-2 if dtype == torch.bfloat16 else 1e-4, reps=8, what=f"attention {B}x{N}x{H}x{hd}")
+
+
+def test_row_kernels_are_repeatable(ops):
+    M, D = 12608, 384
+    x = (_rand(M, D, seed=41) * 1.5 + 0.4).to(torch.bfloat16)
+    w, b = 1.0 + 0.1 * _rand(D, seed=42), 0.1 * _rand(D, seed=43)
+
+    def ln():
+        out = torch.full((M, D), float("nan"), dtype=torch.bfloat16, device=DEV)
+        ops.layernorm(x, out, M, D, w, b, 1e-5)
+        return out
+    _repeat(ln, F.layer_norm(x.float(), (D,), w, b, 1e-5), what="layernorm")
+    _repeat(lambda: ops.ln_stats(x, M, D, 1e-5), what="ln_stats")
+
+    def gelu():
+        out = torch.full((M, D), float("nan"), dtype=torch.bfloat16, device=DEV)
+        ops.gelu(x, out, M, D)
+        return out
+    _repeat(gelu, F.gelu(x.float()), what="gelu")
+
+
+@pytest.mark.parametrize("M,N,K", [(6304, 384, 1152), (12608, 1536, 384), (6304, 768, 768)])
+def test_weight_gradient_gemm_is_repeatable(ops, M, N, K):
+    from vitm_amd import _train_ops as T
+    dy = _rand(M, N, seed=51).to(torch.bfloat16)
+    x = _rand(M, K, seed=52).to(torch.bfloat16)
+    ref = dy.float().t() @ x.float()
+
+    def launch():
+        bias = torch.full((N,), float("nan"), dtype=torch.float32, device=DEV)
+        return T.gemm_tn(dy, x, M, N, K, colsum_out=bias), bias
+    _repeat(launch, ref, rel=1e-3, reps=8, what=f"gemm_tn {M}x{N}x{K}")
+
+
+@pytest.mark.parametrize("B,N,H,hd", [(32, 197, 6, 64), (16, 197, 12, 64), (64, 65, 8, 96)])
+def test_attention_backward_is_repeatable(ops, B, N, H, hd):
+    from vitm_amd import _train_ops as T
+    D = H * hd
+    qkv = _rand(B * N, 3 * D, seed=61).to(torch.bfloat16)
+    d_o = _rand(B * N, D, seed=62).to(torch.bfloat16)
+    o = torch.empty((B * N, D), dtype=torch.bfloat16, device=DEV)
+    lse = torch.empty(B * H * N, dtype=torch.float32, device=DEV)
+    T.attention_lse(qkv, o, lse, B, N, H, hd, hd ** -0.5)
+
+    def launch():
+        dqkv = torch.full((B * N, 3 * D), float("nan"), dtype=torch.bfloat16, device=DEV)
+        T.attention_bwd(qkv, o, d_o, lse, dqkv, B, N, H, hd, hd ** -0.5)
+        return dqkv
+    _repeat(launch, reps=8, what=f"attention backward {B}x{N}x{H}x{hd}")

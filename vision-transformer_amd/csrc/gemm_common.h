@@ -77,8 +77,19 @@ struct EpiCols {
   template <int OUT_F32>
   __device__ __forceinline__ void finish_pre(const GemmArgs& p, int m, int n, float* v, u16x8_t rv, float2 st) const {
     if (EPI == VITM_EPI_LN || EPI == VITM_EPI_LN_GELU) {
+      // rstd * (acc - mean * s) + c as two plain v_fma_f32 per value, issued from inline asm on purpose.  Left to the
+      // compiler this becomes v_pk_fma_f32 with the row's mean / rstd broadcast to both halves, and that form was seen
+      // to lose the product of its LOW half in lanes 48..63 now and then (the output came out as c[n] bit for bit, with
+      // every operand register correct when read back afterwards) whenever a second workgroup of this kernel shared the
+      // CU: 100 .. 400 wrong elements per launch at M = 6304, N = 1152, K = 384, none with one workgroup per CU, none
+      // with the unpacked instruction (tests/test_gpu_kernels.py::test_gemm_small_tile_is_repeatable).
+      const float nmean = -st.x;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = fmaf(fmaf(-sv[e], st.x, v[e]), st.y, cv[e]);  // rstd * (acc - mean * s) + c
+      for (int e = 0; e < 8; ++e) {
+        float t;
+        asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(t) : "v"(sv[e]), "v"(nmean), "v"(v[e]));
+        asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(v[e]) : "v"(t), "v"(st.y), "v"(cv[e]));
+      }
     } else if (EPI == VITM_EPI_BIAS || EPI == VITM_EPI_BIAS_GELU) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] += cv[e];
