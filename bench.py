@@ -39,37 +39,44 @@ import weights as W  # noqa: E402
 
 PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA, MI355X
 PEAK_HBM_GBS = 8000.0
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r2_fc1_traffic.json")  # PMC-measured HBM bytes per fc1 launch
-
-
-def measured_traffic(config, batch):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (None when the
-    committed measurement is for another workload)."""
-    try:
-        with open(TRAFFIC_FILE) as f:
-            t = json.load(f)
-        if t.get("config") == config and t.get("batch_per_gpu") == batch:
-            return t.get("hbm_bytes_per_launch")
-    except (OSError, ValueError):
-        pass
-    return None
-
-
 ALGO_BYTES_PER_IMAGE = {"vit_b16": 79.9e6, "vit_s16": 39.9e6, "vit_b16_384": 234e6}   # per-op-fused bf16 intermediates
-FORWARD_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r2_forward_traffic.json")
 
 
-def measured_forward_traffic(config, batch):
-    """HBM bytes per image over the whole forward (sum over kernels of PMC bytes x calls) from the committed
-    rocprofv3 --pmc passes; None when the committed measurement is for another workload."""
-    try:
-        with open(FORWARD_TRAFFIC_FILE) as f:
-            t = json.load(f)
-        if t.get("config") == config and t.get("batch_per_gpu") == batch:
-            return t.get("hbm_bytes_per_image")
-    except (OSError, ValueError):
-        pass
-    return None
+def csrc_digest():
+    """sha256 over the kernel sources the loaded library is built from (file names and contents, sorted): the identity
+    the committed counter files are checked against.  Same function in profiles/summarize.py."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "vision-transformer_amd", "csrc")
+    for path in sorted(glob.glob(os.path.join(d, "*.hip")) + glob.glob(os.path.join(d, "*.h")) + glob.glob(os.path.join(d, "*.cpp"))):
+        h.update(os.path.basename(path).encode())
+        with open(path, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def committed_counters(kind, config, batch):
+    """(value, note) from the newest profiles/r*_<kind>_traffic.json that was collected for this workload: the PMC
+    figure when that file was collected on these very kernel sources, else (None, why) -- a counter reading of other
+    kernels is not a measurement of these."""
+    import glob
+    key = {"fc1": "hbm_bytes_per_launch", "forward": "hbm_bytes_per_image"}[kind]
+    note = f"no committed rocprofv3 --pmc collection for {config} at batch {batch}"
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{kind}_traffic.json")), reverse=True):
+        try:
+            with open(path) as f:
+                t = json.load(f)
+        except (OSError, ValueError):
+            continue
+        if t.get("config") != config or t.get("batch_per_gpu") != batch:
+            continue
+        name = os.path.basename(path)
+        if t.get("csrc_sha256") != csrc_digest():
+            return None, (f"{name} was collected on other kernel sources (csrc {t.get('csrc_sha256')}, commit "
+                          f"{t.get('commit')}; this tree: csrc {csrc_digest()}): stale, not reported")
+        return t.get(key), f"{name}, commit {t.get('commit')}, csrc {t.get('csrc_sha256')}"
+    return None, note
 
 
 def build_model(cfg, device, seed=0):
@@ -96,7 +103,8 @@ def flops_per_image(shp: dict) -> float:
             + 2.0 * D * C)
 
 def cpu_baseline(cfg, sd, budget_s=15.0, batch=8):
-    """fp32 CPU oracle on `batch` images per pass, as many passes as fit the time budget (>= 2)."""
+    """fp32 CPU oracle on `batch` images per pass, as many passes as fit the time budget (>= 2).  The reference's own
+    CPU-runnable case (ViT-tiny on CIFAR-sized images) is timed at its batch of 64."""
     from oracle import vit_oracle as O
     x = torch.from_numpy(W.make_input(cfg, batch, 7))
     ocfg = W.oracle_cfg(cfg)
@@ -110,7 +118,7 @@ def cpu_baseline(cfg, sd, budget_s=15.0, batch=8):
             dt = time.perf_counter() - t0
             if (dt >= budget_s and n >= 2) or n >= 50:
                 break
-    return dict(value=round(n * batch / dt, 2), unit="images/sec", cores=torch.get_num_threads(), kind="port",
+    return dict(value=round(n * batch / dt, 2), unit="images/sec", cores=torch.get_num_threads(), kind="port", batch=batch,
                 sample=f"{n} passes of batch {batch}, fp32 CPU oracle (torch {torch.__version__}), "
                        f"{dt:.1f} s wall; same model and image size as the GPU workload")
 
@@ -390,6 +398,7 @@ def main():
         M, N, K = args.batch * shp["tokens"], shp["hidden"], shp["embed_dim"]
         fc1_tflops = 2.0 * M * N * K / (fc1_ms * 1e-3) / 1e12
         model_tflops = value / world * gflop_img / 1e3
+        fc1_traffic, fc1_note = committed_counters("fc1", args.config, args.batch)
         line = {
             "metric": "images/sec, ViT-B/16 224px bf16 classification forward" if args.config == "vit_b16"
                       else f"images/sec, {args.config} bf16 classification forward",
@@ -405,7 +414,7 @@ def main():
                        "gflop_per_image": round(gflop_img, 3)},
             "roofline": {"bound": "mfma", "achieved": round(fc1_tflops, 1), "peak": PEAK_BF16_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(fc1_tflops / PEAK_BF16_TFLOPS, 4),
-                         "traffic": measured_traffic(args.config, args.batch),
+                         "traffic": fc1_traffic, "traffic_source": fc1_note,
                          "kernel": "gemm_pp_shared_kernel<EPI_LN_GELU> (fc1: LayerNorm-folded 256x256 ping-pong GEMM + GELU; whole tiles and the leftover-tile slices in one launch)",
                          "flops_per_launch": 2.0 * M * N * K, "avg_launch_ms": round(fc1_ms, 4),
                          "launches_timed": n_launch,
@@ -425,12 +434,12 @@ def main():
         line["roofline"]["hipblaslt_4096_tflops"] = round(blaslt, 1)
         line["roofline"]["frac_of_hipblaslt_4096"] = round(fc1_tflops / blaslt, 4)
         line["whole_forward"]["frac_of_hipblaslt_4096"] = round(model_tflops / blaslt, 4)
-        wf = measured_forward_traffic(args.config, args.batch)
-        if wf is not None:
-            line["whole_forward"]["hbm_bytes_per_image_measured"] = wf
-            line["whole_forward"]["hbm_bytes_per_image_algorithmic"] = ALGO_BYTES_PER_IMAGE.get(args.config)
+        wf, wf_note = committed_counters("forward", args.config, args.batch)
+        line["whole_forward"]["hbm_bytes_per_image_measured"] = wf
+        line["whole_forward"]["hbm_bytes_per_image_source"] = wf_note
+        line["whole_forward"]["hbm_bytes_per_image_algorithmic"] = ALGO_BYTES_PER_IMAGE.get(args.config)
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(cfg, sd)
+            line["cpu_baseline"] = cpu_baseline(cfg, sd, batch=64 if args.config == "vit_tiny_cifar" else 8)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -1,19 +1,25 @@
 #!/bin/bash
-# Profile collection for one round (run on the GPU box from the repo root):  bash profiles/collect.sh r2 [passes]
-# passes: any of trace fetch write sq train (default: all).  A pass that is killed at its time limit ends the script;
-# run the missing passes again in a call of their own.
+# Profile collection for one round (run on the GPU box from the repo root):
+#     bash profiles/collect.sh r3 [passes] [config] [batch]
+# passes: any of trace fetch write sq train (default: all).  config / batch: a bench.py workload other than the headline
+# one (vit_s16 256, vit_b16_384 64 ...); its output goes to gpurun_out/prof_<round>_<config>.  A pass that is killed at
+# its time limit ends the script; run the missing passes again in a call of their own.
 # Pass 1: kernel trace + stats of the bench command.  Passes 2-4: PMC counters, each in a run of its own with
 # kernel-trace only (TCC FETCH_SIZE and WRITE_SIZE do not fit one pass; SQ counters a third).
 set -e
-R=${1:-r2}
+R=${1:-r3}
 PASSES=${2:-"trace fetch write sq train"}
+CONFIG=${3:-vit_b16}
+BATCH=${4:-256}
 OUT=gpurun_out/prof_$R
+if [ "$CONFIG" != vit_b16 ]; then OUT=gpurun_out/prof_${R}_$CONFIG; fi
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-BENCH="python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline"
+WL="--config $CONFIG --batch $BATCH"
+BENCH="python3 bench.py $WL --steps 10 --warmup 3 --no-cpu-baseline"
 # counter passes: no long warm-up.  With counters on, every dispatch is serialised by the profiler, and a queue
 # thousands of kernels deep (the 2-second warm-up) was seen to stall the profiled process for good
-SHORT="python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --warm-seconds 0 --min-timed-seconds 0"
+SHORT="python3 bench.py $WL --steps 2 --warmup 1 --no-cpu-baseline --warm-seconds 0 --min-timed-seconds 0"
 want() { case " $PASSES " in *" $1 "*) echo "pass $1: $(date +%T)" >> $OUT/progress.log; return 0;; esac; return 1; }
 if want trace; then
   rm -rf $OUT/trace

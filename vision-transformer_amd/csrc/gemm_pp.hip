@@ -775,8 +775,10 @@ __device__ __forceinline__ void tile_loop(const GemmArgs& p, char* smem) {
   }
 }
 
-// Whole tiles only (every tile of the launch when nothing is shared).
-template <int EPI, bool STATS = false, bool IM2COL = false>
+// Whole tiles only (every tile of the launch when nothing is shared).  KDEEP (here and below) changes no code: it
+// gives the K > 1024 launches of the moments-writing RESIDUAL epilogue (fc2) a kernel name of their own, so that a
+// kernel trace shows them apart from the K <= 1024 ones (proj), which otherwise share every template argument.
+template <int EPI, bool STATS = false, bool IM2COL = false, bool KDEEP = false>
 __global__ __launch_bounds__(NT, 2) void gemm_pp_kernel(const GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   tile_loop<EPI, 8, false, STATS, IM2COL>(p, smem);
@@ -785,7 +787,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_pp_kernel(const GemmArgs p) {
 // Whole rounds, then this workgroup's slice of a shared leftover tile (NBLK_S 16-row blocks of both wave groups), in
 // one launch: a workgroup moves on to its slice as soon as its own whole tiles are done, instead of waiting at a kernel
 // boundary for the slowest workgroup of the chip.
-template <int EPI, int NBLK_S, bool STATS = false, bool IM2COL = false>
+template <int EPI, int NBLK_S, bool STATS = false, bool IM2COL = false, bool KDEEP = false>
 __global__ __launch_bounds__(NT, 2) void gemm_pp_shared_kernel(const GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   tile_loop<EPI, 8, false, STATS, IM2COL>(p, smem);
@@ -794,14 +796,14 @@ __global__ __launch_bounds__(NT, 2) void gemm_pp_shared_kernel(const GemmArgs p)
   tile_loop<EPI, NBLK_S, true, STATS, IM2COL>(p, smem);
 }
 
-template <int EPI, int NBLK_S, bool STATS = false, bool IM2COL = false>   // NBLK_S = 8: nothing shared
+template <int EPI, int NBLK_S, bool STATS = false, bool IM2COL = false, bool KDEEP = false>   // NBLK_S = 8: nothing shared
 int launch_one(const GemmArgs& b, int grid, hipStream_t st) {
   if constexpr (NBLK_S == 8) {
-    auto kfn = gemm_pp_kernel<EPI, STATS, IM2COL>;
+    auto kfn = gemm_pp_kernel<EPI, STATS, IM2COL, KDEEP>;
     VITM_LDS_OPTIN(kfn, SMEM, "vitm_gemm");
     hipLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3(NT), SMEM, st, b);
   } else {
-    auto kfn = gemm_pp_shared_kernel<EPI, NBLK_S, STATS, IM2COL>;
+    auto kfn = gemm_pp_shared_kernel<EPI, NBLK_S, STATS, IM2COL, KDEEP>;
     VITM_LDS_OPTIN(kfn, SMEM, "vitm_gemm");
     hipLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3(NT), SMEM, st, b);
   }
@@ -810,12 +812,12 @@ int launch_one(const GemmArgs& b, int grid, hipStream_t st) {
 }
 
 // S workgroups per leftover tile -> blocks per slice
-template <int EPI, bool STATS, bool IM2COL>
+template <int EPI, bool STATS, bool IM2COL, bool KDEEP = false>
 int launch_shared(const GemmArgs& b, int grid, int S, hipStream_t st) {
   switch (S) {
-    case 2: return launch_one<EPI, 4, STATS, IM2COL>(b, grid, st);
-    case 3: return launch_one<EPI, 3, STATS, IM2COL>(b, grid, st);
-    default: return launch_one<EPI, 2, STATS, IM2COL>(b, grid, st);
+    case 2: return launch_one<EPI, 4, STATS, IM2COL, KDEEP>(b, grid, st);
+    case 3: return launch_one<EPI, 3, STATS, IM2COL, KDEEP>(b, grid, st);
+    default: return launch_one<EPI, 2, STATS, IM2COL, KDEEP>(b, grid, st);
   }
 }
 
@@ -859,6 +861,7 @@ int launch(const GemmArgs& a, hipStream_t st) {
   b.S = S;
   if (EPI == VITM_EPI_RESIDUAL && b.stats_out != nullptr) {
     constexpr int E = VITM_EPI_RESIDUAL;   // the only epilogue whose output feeds a LayerNorm
+    if (a.K > 1024) return b.share ? launch_shared<E, true, false, true>(b, grid, S, st) : launch_one<E, 8, true, false, true>(b, grid, st);
     return b.share ? launch_shared<E, true, false>(b, grid, S, st) : launch_one<E, 8, true>(b, grid, st);
   }
   if constexpr (EPI == VITM_EPI_BIAS) {
