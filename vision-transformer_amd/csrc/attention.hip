@@ -276,6 +276,62 @@ __device__ __forceinline__ void pair_done() {   // this wave's DMA landed, then 
   __builtin_amdgcn_s_barrier();
 }
 
+// The mover's copy of NPC 8-row pieces of K and NPC of V (rows k0 .. of one (image, head), clamped to row N - 1) into a
+// ring entry, through registers: all 2 NPC 16-byte loads of the lane are issued first (up to 56 KiB per CU in flight),
+// then written to LDS as they return.  An LDS-DMA piece occupies the issuing wave for ~165 cycles, which capped the one
+// mover wave at ~6 B/clk -- less than the computing waves consume at 577 tokens (56 KiB per 224-key chunk); a 1-KiB
+// register load plus its LDS write costs the wave a third of that, and the mover has the whole register budget of the
+// kernel to itself.  Same byte placement as the DMA form: piece pl of an operand lands at pl * 1024 + 16 * lane.
+template <int NPC>
+__device__ __forceinline__ void stage_kv(const bf16_t* base, int64_t ldq, int D, int k0, int N, int lane, char* dst) {
+  const int lr = lane >> 3;
+  const int kcol0 = ((lane & 7) ^ ((lane >> 4) & 3)) * 8;        // K chunk swizzle: (row >> 1) & 7, row = 8 pl + lr
+  const int kcol1 = ((lane & 7) ^ (((lane >> 4) & 3) | 4)) * 8;  //   odd pieces
+  const int vcol = ((lane & 7) ^ (4 * ((lane >> 4) & 1))) * 8;   // V chunk swizzle: 4 * ((row >> 1) & 1)
+  typedef __attribute__((ext_vector_type(4))) unsigned q4_t;   // (a HIP uint4 array is not promoted to registers)
+  q4_t buf[2 * NPC];   // K pieces 0 .. NPC - 1, then V
+#pragma unroll
+  for (int p = 0; p < 2 * NPC; ++p) {
+    const int pl = p < NPC ? p : p - NPC;
+    int row = k0 + pl * 8 + lr;
+    row = row < N ? row : N - 1;
+    buf[p] = *(const q4_t*)(base + (int64_t)row * ldq + (p < NPC ? D + ((pl & 1) ? kcol1 : kcol0) : 2 * D + vcol));
+  }
+#pragma unroll
+  for (int p = 0; p < 2 * NPC; ++p) {
+    const int pl = p < NPC ? p : p - NPC;
+    *(q4_t*)(dst + (p < NPC ? 0 : PARTB) + pl * 1024 + lane * 16) = buf[p];
+  }
+}
+// The mover's copy of the 7 x 32 query rows q00 .. of one (image, head) into the computing waves' 4-KiB regions at `qdst`
+// (blocks that start past N are skipped), in the layout those waves read: piece j of a block = rows 8 j .. 8 j + 7, 16-byte
+// chunks XOR-ed with (row >> 1) & 7.
+__device__ __forceinline__ void stage_q(const bf16_t* base, int64_t ldq, int q00, int N, int lane, char* qdst, int nblocks, int region) {
+  typedef __attribute__((ext_vector_type(4))) unsigned q4_t;
+  q4_t qb[28];
+#pragma unroll
+  for (int w = 0; w < 7; ++w) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int rl = 8 * j + (lane >> 3);
+      int row = q00 + 32 * w + rl;
+      row = row < N ? row : N - 1;
+      if (w < nblocks && q00 + 32 * w < N) qb[4 * w + j] = *(const q4_t*)(base + (int64_t)row * ldq + (((lane & 7) ^ ((rl >> 1) & 7)) * 8));
+    }
+  }
+#pragma unroll
+  for (int w = 0; w < 7; ++w) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (w < nblocks && q00 + 32 * w < N) *(q4_t*)(qdst + w * region + j * 1024 + lane * 16) = qb[4 * w + j];
+  }
+}
+// the mover's end of a pair / chunk: its LDS writes are done, then everyone is done with the previous entry
+__device__ __forceinline__ void mover_done() {
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+}
+
 // WITH_LSE: also write the log-sum-exp of every query row (training); it is formed from the fp32 probabilities
 // (a VALU sum on top), while the output is normalised by the sum of the bf16 ones either way.
 template <int NT, bool WITH_LSE>   // key tiles of 32: 32 (NT - 1) < N <= 32 NT
@@ -299,6 +355,8 @@ __global__ __launch_bounds__(NTH, 2) void attn_short_kernel(const bf16_t* __rest
   if (wave == CWAVES) {
     // ---- the mover: K rows then V rows of pair k + 1 into ring entry (k + 1) & 1 while pair k is computed.  Rows
     // past N repeat row N - 1 (finite values: their scores are masked and their probabilities are exactly 0).
+    // By LDS-DMA: here the mover has a whole pair's time for 56 pieces, and staged through registers (stage_kv, what
+    // the chunked kernel below does) the same copy measured 4 % slower at 197 tokens.
     const int lr = lane >> 3;
     const int kcol0 = ((lane & 7) ^ ((lane >> 4) & 3)) * 8;        // K chunk swizzle: (row >> 1) & 7, row = 8 pl + lr
     const int kcol1 = ((lane & 7) ^ (((lane >> 4) & 3) | 4)) * 8;  //   odd pieces
@@ -535,6 +593,16 @@ __global__ __launch_bounds__(NTH, 2) void attn_short_kernel(const bf16_t* __rest
 // the strip; across chunks a running maximum rescales O and the row sums once per chunk (2-3 times per item at 577
 // tokens, against 18 times per item for a tile-by-tile online softmax).  The query groups of one (image, head) are
 // dealt to workgroups of one XCD (blockIdx & 7), so their K / V chunks are fetched from memory once and then from L2.
+#ifdef ATTN_STAMP   // chunked kernel: record [workgroup][step < 16][wave][slot < 8]
+#define CSTAMP(kk)                                                                                      \
+  do {                                                                                                  \
+    unsigned long long t__;                                                                             \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__)::"memory");                          \
+    if (lane == 0 && step < 16) ((unsigned long long*)lse)[(((size_t)blockIdx.x * 16 + step) * 8 + wave) * 8 + (kk)] = t__; \
+  } while (0)
+#else
+#define CSTAMP(kk) do {} while (0)
+#endif
 template <int NTL, bool WITH_LSE>   // NTL: key tiles of the LAST chunk, 32 (NTL - 1) < N - 224 (nchunks - 1) <= 32 NTL
 __global__ __launch_bounds__(NTH, 2) void attn_chunked_kernel(const bf16_t* __restrict__ qkv, int64_t ldq,
                                                               bf16_t* __restrict__ out, int64_t ldo, int N, int H,
@@ -566,36 +634,31 @@ __global__ __launch_bounds__(NTH, 2) void attn_chunked_kernel(const bf16_t* __re
 
   if (wave == CWAVES) {
     // ---- the mover: chunk (step % nchunks) of item (step / nchunks) into ring entry step & 1, one step ahead
-    const int lr = lane >> 3;
-    const int kcol0 = ((lane & 7) ^ ((lane >> 4) & 3)) * 8;
-    const int kcol1 = ((lane & 7) ^ (((lane >> 4) & 3) | 4)) * 8;
-    const int vcol = ((lane & 7) ^ (4 * ((lane >> 4) & 1))) * 8;
     const int nsteps = my_items * nchunks;
-    auto move_step = [&](int step) {
+      auto move_step = [&](int step) {
       const int k = step / nchunks, c = step - k * nchunks;
       int unit, qg;
       item_of(k, unit, qg);
-      const bf16_t* base = unit_base(unit);
-      const int k0 = c * CK;
-      const int rows = N - k0 < CK ? N - k0 : CK;
-      const int np = ((rows + 31) >> 5) * 4;
-      const unsigned dst = lds0 + (step & 1) * BUFB;
-      for (int pl = 0; pl < np; ++pl) {
-        int row = k0 + pl * 8 + lr;
-        row = row < N ? row : N - 1;
-        glds16(base + (int64_t)row * ldq + D + ((pl & 1) ? kcol1 : kcol0), dst + pl * 1024);
-      }
-      for (int pl = 0; pl < np; ++pl) {
-        int row = k0 + pl * 8 + lr;
-        row = row < N ? row : N - 1;
-        glds16(base + (int64_t)row * ldq + 2 * D + vcol, dst + PARTB + pl * 1024);
-      }
+      char* dst = smem + (step & 1) * BUFB;
+      if (c + 1 < nchunks) stage_kv<4 * MAX_TILES>(unit_base(unit), ldq, D, c * CK, N, lane, dst);
+      else stage_kv<4 * NTL>(unit_base(unit), ldq, D, c * CK, N, lane, dst);
+    };
+    // Q rows of item k for all computing waves.  The regions are free from the flush of the previous item's output
+    // (after the S phase of an item's first chunk) to the start of the next item, so the rows of item k + 1 are brought
+    // during the second chunk of item k, behind that chunk's barrier
+    auto move_q = [&](int k) {
+      int unit, qg;
+      item_of(k, unit, qg);
+      stage_q(unit_base(unit), ldq, qg * CK, N, lane, smem + QBASE, CWAVES, QREG);
     };
     move_step(0);
-    pair_done();
+    move_q(0);
+    mover_done();
     for (int step = 0; step < nsteps; ++step) {
       if (step + 1 < nsteps) move_step(step + 1);
-      pair_done();
+      const int k = step / nchunks;
+      if (step - k * nchunks == 1 && k + 1 < my_items) move_q(k + 1);
+      mover_done();
     }
     return;
   }
@@ -610,30 +673,15 @@ __global__ __launch_bounds__(NTH, 2) void attn_chunked_kernel(const bf16_t* __re
 #pragma unroll
   for (int d = 0; d < 2; ++d)
     voff[d] = (4 * hh + (li >> 2)) * RS + 64 * (d ^ ((li >> 3) & 1)) + 32 * (g16 & 1) + 8 * (li & 3);
-  int ooff[4], qcol[4];
+  int ooff[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int row = 8 * i + (lane >> 3);
     const int sw = (row >> 1) & 7;
     ooff[i] = row * RS + (((lane & 7) ^ sw) * 16);
-    qcol[i] = ((lane & 7) ^ sw) * 8;
   }
   char* const qreg = smem + QBASE + wave * QREG;
   const unsigned qreg_lds = lds0 + QBASE + wave * QREG;
-  auto issue_q = [&](int k) {   // Q rows of this wave's block of item k (nothing when the block lies past N)
-    int unit, qg;
-    item_of(k, unit, qg);
-    const int q0 = qg * CK + wave * 32;
-    if (q0 >= N) return;
-    const bf16_t* base = unit_base(unit);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      int row = q0 + 8 * j + (lane >> 3);
-      row = row < N ? row : N - 1;
-      glds16(base + (int64_t)row * ldq + qcol[j], qreg_lds + j * 1024);
-    }
-  };
-
   uint4 ost0, ost1, ost2, ost3;
   ost0 = ost1 = ost2 = ost3 = make_uint4(0, 0, 0, 0);
   bf16_t* pend = nullptr;   // first row of the packed tile waiting in ost0..3 (wave-uniform), with its first query
@@ -657,7 +705,6 @@ __global__ __launch_bounds__(NTH, 2) void attn_chunked_kernel(const bf16_t* __re
     pend = nullptr;                                                                                   \
   } while (0)
 
-  issue_q(0);
   pair_done();
 
   int step = 0;
@@ -667,8 +714,8 @@ __global__ __launch_bounds__(NTH, 2) void attn_chunked_kernel(const bf16_t* __re
     const int q0 = qg * CK + wave * 32;
     const bool active = q0 < N;   // wave-uniform
     const bool more = k + 1 < my_items;
-    if (!active) {                // no queries for this wave in this item: keep the barrier count and the Q hand-over
-      if (more) issue_q(k + 1);
+    if (!active) {                // no queries for this wave in this item: keep the barrier count
+      if (pend != nullptr) VITM_FLUSH_PENDING();
       for (int c = 0; c < nchunks; ++c, ++step) pair_done();
       continue;
     }
@@ -676,19 +723,20 @@ __global__ __launch_bounds__(NTH, 2) void attn_chunked_kernel(const bf16_t* __re
 #pragma unroll
     for (int s = 0; s < 4; ++s) qf[s] = *(const bf16x8_t*)(qreg + koff[s]);
     wait_lds();
-    // the region is free (Q is in registers): previous output through it, then the next item's Q into it
-    if (pend != nullptr) VITM_FLUSH_PENDING();
-    if (more) issue_q(k + 1);
+    CSTAMP(5);
+    // the region is free now (Q is in registers): the previous item's output goes through it after the S phase of the
+    // first chunk, and the mover refills it with the next item's Q rows during the second chunk
     f32x16_t o[2];
 #pragma unroll
     for (int e = 0; e < 16; ++e) o[0][e] = o[1][e] = 0.f;
     float m_run = -1e30f, lsum = 0.f;   // lsum: this half's share of the row sum (fp32 probabilities)
 
     // one chunk of NTC key tiles out of ring entry step & 1
-    auto chunk = [&](auto ntc_tag, int keys) {
+    auto chunk = [&](auto ntc_tag, int keys, bool first) {
       constexpr int NTC = decltype(ntc_tag)::value;
       const char* Kb = smem + (step & 1) * BUFB;
       const char* Vb = Kb + PARTB;
+      CSTAMP(0);
       // K fragments half a tile ahead (two of a tile's four k-steps): the registers that a whole tile ahead would
       // take are held by O here
       bf16x8_t kf[2][2];
@@ -718,6 +766,9 @@ __global__ __launch_bounds__(NTH, 2) void attn_chunked_kernel(const bf16_t* __re
           if (key >= keys) sacc[NTC - 1][e] = -1e30f;
         }
       }
+      CSTAMP(1);
+      if (first && pend != nullptr) VITM_FLUSH_PENDING();   // the stores go out while the softmax runs
+      CSTAMP(6);
       float m = sacc[0][0];
 #pragma unroll
       for (int t = 0; t < NTC; ++t)
@@ -725,6 +776,7 @@ __global__ __launch_bounds__(NTH, 2) void attn_chunked_kernel(const bf16_t* __re
         for (int e = 0; e < 16; ++e) m = fmaxf(m, sacc[t][e]);
       float m_own, m_other;
       half_pair(m, m_own, m_other);
+      CSTAMP(2);
       const float m_new = fmaxf(m_run, fmaxf(m_own, m_other));
       const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * sl2e);   // 0 for the first chunk
       m_run = m_new;
@@ -778,18 +830,22 @@ __global__ __launch_bounds__(NTH, 2) void attn_chunked_kernel(const bf16_t* __re
 
     for (int c = 0; c < nchunks; ++c, ++step) {
       if (c + 1 < nchunks) {
-        chunk(std::integral_constant<int, MAX_TILES>{}, CK);
+        chunk(std::integral_constant<int, MAX_TILES>{}, CK, c == 0);
+        CSTAMP(3);
         pair_done();
+        CSTAMP(4);
       } else {
-        chunk(std::integral_constant<int, NTL>{}, N - c * CK);
+        chunk(std::integral_constant<int, NTL>{}, N - c * CK, false);
         // ---- the item is complete: normalise, pack (see attn_short_kernel)
         float ls_own, ls_other;
         half_pair(lsum, ls_own, ls_other);
         const float l = ls_own + ls_other;
         const float inv = __builtin_amdgcn_rcpf(l);
+#ifndef ATTN_STAMP
         if (WITH_LSE) {
           if (hh == 0 && q0 + r < N) lse[(int64_t)unit * N + q0 + r] = m_run * sl2e + __log2f(l);
         }
+#endif
 #define VITM_PACK_OUT(dst, d, pq)                                                          \
   do {                                                                                    \
     unsigned a0 = pack_bf2(o[d][8 * pq + 0] * inv, o[d][8 * pq + 1] * inv);               \
@@ -808,7 +864,9 @@ __global__ __launch_bounds__(NTH, 2) void attn_chunked_kernel(const bf16_t* __re
         const int b = unit / H, h = unit - b * H;
         pend = out + ((int64_t)b * N + q0) * ldo + h * HD;
         pend_q0 = q0;
+        CSTAMP(3);
         pair_done();
+        CSTAMP(4);
       }
     }
   }
