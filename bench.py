@@ -402,6 +402,8 @@ def main():
         fc1_tflops = 2.0 * M * N * K / (fc1_ms * 1e-3) / 1e12
         model_tflops = value / world * gflop_img / 1e3
         fc1_traffic, fc1_note = committed_counters("fc1", args.config, args.batch)
+        from vitm_amd import _lib
+        big_tile = bool(_lib.load().vitm_gemm_uses_big_tile(M, (N + 7) // 8 * 8, (K + 63) // 64 * 64))
         line = {
             "metric": "images/sec, ViT-B/16 224px bf16 classification forward" if args.config == "vit_b16"
                       else f"images/sec, {args.config} bf16 classification forward",
@@ -418,7 +420,8 @@ def main():
             "roofline": {"bound": "mfma", "achieved": round(fc1_tflops, 1), "peak": PEAK_BF16_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(fc1_tflops / PEAK_BF16_TFLOPS, 4),
                          "traffic": fc1_traffic, "traffic_source": fc1_note,
-                         "kernel": "gemm_pp_shared_kernel<EPI_LN_GELU> (fc1: LayerNorm-folded 256x256 ping-pong GEMM + GELU; whole tiles and the leftover-tile slices in one launch)",
+                         "kernel": ("gemm_pp[_shared]_kernel<EPI_LN_GELU> (fc1: LayerNorm-folded 256x256 ping-pong GEMM + GELU; whole tiles and any leftover-tile slices in one launch)"
+                                    if big_tile else "gemm_kernel<EPI_LN_GELU> (fc1: LayerNorm-folded 128x128-tile GEMM + GELU; this shape is too small for the 256x256 kernel)"),
                          "flops_per_launch": 2.0 * M * N * K, "avg_launch_ms": round(fc1_ms, 4),
                          "launches_timed": n_launch,
                          # what two event records cost with nothing between them, measured right behind each launch:

@@ -17,8 +17,15 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 WL="--config $CONFIG --batch $BATCH"
 BENCH="python3 bench.py $WL --steps 10 --warmup 3 --no-cpu-baseline"
-# counter passes: no long warm-up.  With counters on, every dispatch is serialised by the profiler, and a queue
-# thousands of kernels deep (the 2-second warm-up) was seen to stall the profiled process for good
+# counter passes: no long warm-up.  What was seen (round 2, no log kept): the --pmc passes run with the FULL bench command
+# (~23 k dispatches, ~13 k of them queued by the 2-second warm-up before the first synchronize) did not finish inside
+# their 150-200 s limits, while the kernel-trace pass of the same command always finished in ~5 s.  With counters on the
+# profiler serialises every dispatch (the short command's ~1 k dispatches take a counter pass ~3 s, start-up included:
+# on the order of a millisecond each, growing with the depth of the queue).  The library's kernels cannot be what stood
+# still: none waits on another workgroup (s_barrier inside a workgroup is their only synchronisation; there is no atomic
+# and no spin loop in csrc/), and the same launches complete under the trace pass and in every test.  Hence the short
+# command below; VITM_BENCH_WATCHDOG=<s> (stack dump and exit) and VITM_SYNC_DEBUG=1 (name and wait for every call) are
+# there to name the call in flight should a pass ever stand still again.
 SHORT="python3 bench.py $WL --steps 2 --warmup 1 --no-cpu-baseline --warm-seconds 0 --min-timed-seconds 0"
 want() { case " $PASSES " in *" $1 "*) echo "pass $1: $(date +%T)" >> $OUT/progress.log; return 0;; esac; return 1; }
 if want trace; then
