@@ -261,6 +261,15 @@ __device__ __forceinline__ void glds16(const void* g, unsigned lds_addr) {
                : "v"(g), "s"(lds_addr)
                : "memory");
 }
+// 4 bytes per lane (256 B per wave) by LDS-DMA: used to pull 64 different cache lines towards L2 with one instruction;
+// the bytes themselves land in a scratch corner of LDS and are never read
+__device__ __forceinline__ void glds4(const void* g, unsigned lds_addr) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(g), "s"(lds_addr)
+               : "memory");
+}
 // a value and that of lane ^ 32, without the LDS crossbar (v_permlane32_swap of two copies)
 __device__ __forceinline__ void half_pair(float x, float& own, float& other) {
   own = x;
@@ -899,9 +908,306 @@ int launch_chunked(const void* qkv, int64_t ldq, void* out, int64_t ldo, int B, 
   return VITM_OK;
 }
 
+
+// ---- 225 .. 608 tokens (head_dim 64; ViT-B/16 at 384 pixels: 577): all K and V rows of an (image, head) stay in LDS ----
+// 19 key tiles x 32 rows x 128 B x 2 operands = 152 KiB: with nothing else in LDS a whole (image, head) fits, so a
+// workgroup loads its K / V once (the chunked kernel's three query-group workgroups each streamed them) and, more
+// important, there is no per-chunk barrier: a wave takes the 32-query blocks w, w + 8, w + 16 of the unit and runs them
+// at its own pace.  The chunked kernel's barrier after every 224 keys re-aligned the phases of the two waves of a SIMD at
+// every step (both on the matrix pipe for S, then both on the VALU for the softmax) and made the four older waves wait
+// ~3 k cycles of every 8.3 k for the younger ones; left alone the waves drift apart and the pipes overlap.
+// All 8 waves compute.  Q fragments come straight from global memory into registers (the next block's rows are requested
+// right after the last S phase of the current block, when the fragment registers fall free), and the output tile is
+// stored from registers as 32-byte segments (four instructions fill a row's 128-byte line).  Per unit: barrier, the 8
+// waves bring K and V by LDS-DMA (19 pieces each), barrier.  Within a block the softmax is the strip-wise one of the
+// chunked kernel: exact over 224 keys, a running maximum and one rescale of O per further 224.
+constexpr int RES_MAX_TILES = 19;
+constexpr int RES_OPB = RES_MAX_TILES * 32 * RS;      // K (or V) rows of one unit: 76 KiB
+constexpr int RES_SMEM = 2 * RES_OPB + 8 * 256;       // 152 KiB + a 256-byte sink per wave for the prefetch
+
+template <int NTL, bool WITH_LSE>   // NTL: key tiles of the LAST 224-key strip, as in attn_chunked_kernel
+__global__ __launch_bounds__(512, 2) void attn_resident_kernel(const bf16_t* __restrict__ qkv, int64_t ldq,
+                                                               bf16_t* __restrict__ out, int64_t ldo, int N, int H,
+                                                               float sl2e, int nunits, float* __restrict__ lse) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int CK = 32 * MAX_TILES;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int D = H * HD;
+  const int nchunks = (N + CK - 1) / CK;
+  const int ntiles = (nchunks - 1) * MAX_TILES + NTL;   // key tiles of a unit (<= 19)
+  const int nqb = (N + 31) >> 5;                        // 32-query blocks of a unit
+  const unsigned lds0 = (unsigned)(unsigned long)LPTR(smem);
+  const int r = lane & 31, hh = lane >> 5;
+  const int fk = (r >> 1) & 7;
+  int koff[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) koff[s] = r * RS + (((2 * s + hh) ^ fk) * 16);
+  const int g16 = lane >> 4, li = lane & 15;
+  int voff[2];
+#pragma unroll
+  for (int d = 0; d < 2; ++d)
+    voff[d] = (4 * hh + (li >> 2)) * RS + 64 * (d ^ ((li >> 3) & 1)) + 32 * (g16 & 1) + 8 * (li & 3);
+  // loader constants (see the mover of attn_short_kernel)
+  const int lr = lane >> 3;
+  const int kcol0 = ((lane & 7) ^ ((lane >> 4) & 3)) * 8, kcol1 = ((lane & 7) ^ (((lane >> 4) & 3) | 4)) * 8;
+  const int vcol = ((lane & 7) ^ (4 * ((lane >> 4) & 1))) * 8;
+  const int npieces = 4 * ntiles;   // per operand
+
+#ifdef ATTN_STAMP
+  int ui = 0, bi = 0;
+#define RSTAMP(kk)                                                                                      \
+  do {                                                                                                  \
+    unsigned long long t__;                                                                             \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__)::"memory");                          \
+    if (lane == 0 && ui < 4 && bi < 3) ((unsigned long long*)lse)[((((size_t)blockIdx.x * 4 + ui) * 8 + wave) * 3 + bi) * 8 + (kk)] = t__; \
+  } while (0)
+#else
+#define RSTAMP(kk) do {} while (0)
+#endif
+  // The next unit's K and V rows are touched while this unit is computed (one line per lane, 2 N lines = 19
+  // instructions per unit, dealt over the waves): loading a unit is not overlapped with anything, and read from HBM
+  // its 152 KiB took a CU ~17 k cycles (~10 B/clk) of a unit's ~70 k.
+  auto prefetch_unit = [&](int nu, int i) {   // instruction i of unit nu: lines 64 i .. 64 i + 63 (line = K row, then V row)
+    if (nu >= nunits) return;
+    const int idx = 64 * i + lane;
+    const int nb = nu / H, nh = nu - nb * H;
+    int row = idx < N ? idx : idx - N;
+    row = row < N ? row : N - 1;
+    const bf16_t* src = qkv + (int64_t)nb * N * ldq + nh * HD + (int64_t)row * ldq + (idx < N ? D : 2 * D);
+    glds4(src, lds0 + 2 * RES_OPB + wave * 256);
+  };
+  const int npf = (2 * N + 63) >> 6;   // prefetch instructions per unit
+  for (int unit = blockIdx.x; unit < nunits; unit += gridDim.x) {
+    const int b = unit / H, h = unit - b * H;
+#ifdef ATTN_STAMP
+    bi = 0;
+    RSTAMP(0);
+#endif
+    const bf16_t* base = qkv + (int64_t)b * N * ldq + h * HD;
+    // ---- everyone is done with the previous unit's rows; K and V of this one, piece p by wave p & 7
+    __builtin_amdgcn_s_barrier();
+    for (int pl = wave; pl < npieces; pl += 8) {
+      int row = pl * 8 + lr;
+      row = row < N ? row : N - 1;
+      glds16(base + (int64_t)row * ldq + D + ((pl & 1) ? kcol1 : kcol0), lds0 + pl * 1024);
+      glds16(base + (int64_t)row * ldq + 2 * D + vcol, lds0 + RES_OPB + pl * 1024);
+    }
+    // this wave's first Q fragments: row q0 + r, 16-byte chunk 2 s + hh
+    int qb = wave;
+    bf16x8_t qf[4];
+    auto load_q = [&](int blk) {
+      int row = 32 * blk + r;
+      row = row < N ? row : N - 1;
+      const bf16_t* qp = base + (int64_t)row * ldq + hh * 8;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) qf[s] = *(const bf16x8_t*)(qp + 16 * s);
+    };
+    if (qb < nqb) load_q(qb);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    RSTAMP(1);
+    __builtin_amdgcn_s_barrier();
+    RSTAMP(2);
+
+    for (; qb < nqb; qb += 8) {
+      const int q0 = 32 * qb;
+      RSTAMP(3);
+      f32x16_t o[2];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) o[0][e] = o[1][e] = 0.f;
+      float m_run = -1e30f, lsum = 0.f;   // lsum: this half's share of the row sum (fp32 probabilities)
+
+      // one strip of NTC key tiles starting at key k0; `last`: request the next block's Q once the S phase is issued
+      auto strip = [&](auto ntc_tag, int k0, int keys, bool last) {
+        constexpr int NTC = decltype(ntc_tag)::value;
+        const char* Kb = smem + k0 * RS;
+        const char* Vb = smem + RES_OPB + k0 * RS;
+        bf16x8_t kf[2][2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) kf[0][s] = *(const bf16x8_t*)(Kb + koff[s]);
+        f32x16_t sacc[NTC];
+#pragma unroll
+        for (int t = 0; t < NTC; ++t) {
+#pragma unroll
+          for (int e = 0; e < 16; ++e) sacc[t][e] = 0.f;
+#pragma unroll
+          for (int hs = 0; hs < 2; ++hs) {
+            const int nx = 2 * t + hs + 1;
+            if (nx < 2 * NTC) {
+#pragma unroll
+              for (int s = 0; s < 2; ++s) kf[nx & 1][s] = *(const bf16x8_t*)(Kb + (nx >> 1) * 32 * RS + koff[2 * (nx & 1) + s]);
+            }
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+              sacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[hs][s], qf[2 * hs + s], sacc[t], 0, 0, 0);
+          }
+        }
+        if (last && qb + 8 < nqb) load_q(qb + 8);   // the fragment registers are free from here on
+        if (NTC * 32 > keys) {
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int key = (NTC - 1) * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+            if (key >= keys) sacc[NTC - 1][e] = -1e30f;
+          }
+        }
+        float m = sacc[0][0];
+#pragma unroll
+        for (int t = 0; t < NTC; ++t)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) m = fmaxf(m, sacc[t][e]);
+        float m_own, m_other;
+        half_pair(m, m_own, m_other);
+        const float m_new = fmaxf(m_run, fmaxf(m_own, m_other));
+        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * sl2e);   // 0 for the first strip
+        m_run = m_new;
+        const float mb = m_new * sl2e;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          o[0][e] *= alpha;
+          o[1][e] *= alpha;
+        }
+        float ssum = 0.f;   // this strip's share of the row sum; folded into the running one by ONE explicit fma below (left
+                            // as "lsum *= alpha; lsum += p" the compiler contracts the two differently per instantiation)
+        bf16x8_t pb[NTC][2];
+        const f32x2_t sc2 = {sl2e, sl2e}, nmb2 = {-mb, -mb};
+#pragma unroll
+        for (int t = 0; t < NTC; ++t) {
+#pragma unroll
+          for (int s2 = 0; s2 < 2; ++s2) {
+            unsigned pk[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const f32x2_t x = __builtin_elementwise_fma((f32x2_t){sacc[t][8 * s2 + 2 * j], sacc[t][8 * s2 + 2 * j + 1]}, sc2, nmb2);
+              const float p0 = __builtin_amdgcn_exp2f(x.x), p1 = __builtin_amdgcn_exp2f(x.y);
+              ssum += p0 + p1;
+              pk[j] = pack_bf2(p0, p1);
+            }
+            pb[t][s2] = __builtin_bit_cast(bf16x8_t, make_uint4(pk[0], pk[1], pk[2], pk[3]));
+          }
+        }
+        lsum = __builtin_fmaf(lsum, alpha, ssum);
+        u16x4_t vf[2][4];
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+          vf[0][2 * d] = tr_read(Vb + voff[d]);
+          vf[0][2 * d + 1] = tr_read(Vb + voff[d] + 8 * RS);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2 * NTC; ++ks) {
+          if (ks + 1 < 2 * NTC) {
+#pragma unroll
+            for (int d = 0; d < 2; ++d) {
+              vf[(ks + 1) & 1][2 * d] = tr_read(Vb + (ks + 1) * 16 * RS + voff[d]);
+              vf[(ks + 1) & 1][2 * d + 1] = tr_read(Vb + (ks + 1) * 16 * RS + voff[d] + 8 * RS);
+            }
+          }
+#pragma unroll
+          for (int d = 0; d < 2; ++d) {
+            const u16x4_t lo = vf[ks & 1][2 * d], hi = vf[ks & 1][2 * d + 1];
+            u16x8_t tv;
+            tv[0] = lo[0]; tv[1] = lo[1]; tv[2] = lo[2]; tv[3] = lo[3];
+            tv[4] = hi[0]; tv[5] = hi[1]; tv[6] = hi[2]; tv[7] = hi[3];
+            o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, tv), pb[ks >> 1][ks & 1], o[d], 0, 0, 0);
+          }
+        }
+      };
+
+      for (int c = 0; c + 1 < nchunks; ++c) {
+        strip(std::integral_constant<int, MAX_TILES>{}, c * CK, CK, false);
+#ifndef ATTN_NO_PREFETCH
+        if (c == 0) {   // this wave's share of the next unit's lines: instructions pfi, pfi + 8, ... over its blocks
+          const int blk_i = (qb - wave) >> 3;             // 0, 1, 2: which of this wave's blocks
+          for (int i = wave + 8 * blk_i; i < npf; i += 24) prefetch_unit(unit + gridDim.x, i);
+        }
+#endif
+        RSTAMP(4 + c);
+      }
+      strip(std::integral_constant<int, NTL>{}, (nchunks - 1) * CK, N - (nchunks - 1) * CK, true);
+      RSTAMP(6);
+
+      // ---- normalise, pack (see attn_short_kernel), store: lane (r, hh) holds dims 16 J + 8 hh .. + 7 of query q0 + r
+      float ls_own, ls_other;
+      half_pair(lsum, ls_own, ls_other);
+      const float l = ls_own + ls_other;
+      const float inv = __builtin_amdgcn_rcpf(l);
+#ifndef ATTN_STAMP
+      if (WITH_LSE) {
+        if (hh == 0 && q0 + r < N) lse[(int64_t)unit * N + q0 + r] = m_run * sl2e + __log2f(l);
+      }
+#endif
+      uint4 ost0, ost1, ost2, ost3;
+#define VITM_PACK_OUT(dst, d, pq)                                                          \
+  do {                                                                                    \
+    unsigned a0 = pack_bf2(o[d][8 * pq + 0] * inv, o[d][8 * pq + 1] * inv);               \
+    unsigned a1 = pack_bf2(o[d][8 * pq + 2] * inv, o[d][8 * pq + 3] * inv);               \
+    unsigned b0 = pack_bf2(o[d][8 * pq + 4] * inv, o[d][8 * pq + 5] * inv);               \
+    unsigned b1 = pack_bf2(o[d][8 * pq + 6] * inv, o[d][8 * pq + 7] * inv);               \
+    swap32u(a0, b0);                                                                      \
+    swap32u(a1, b1);                                                                      \
+    dst = make_uint4(a0, a1, b0, b1);                                                     \
+  } while (0)
+      VITM_PACK_OUT(ost0, 0, 0);
+      VITM_PACK_OUT(ost1, 0, 1);
+      VITM_PACK_OUT(ost2, 1, 0);
+      VITM_PACK_OUT(ost3, 1, 1);
+#undef VITM_PACK_OUT
+      if (q0 + r < N) {
+        bf16_t* op = out + ((int64_t)b * N + q0 + r) * ldo + h * HD + 8 * hh;
+        *(uint4*)op = ost0;
+        *(uint4*)(op + 16) = ost1;
+        *(uint4*)(op + 32) = ost2;
+        *(uint4*)(op + 48) = ost3;
+      }
+      RSTAMP(7);
+#ifdef ATTN_STAMP
+      ++bi;
+#endif
+    }
+#ifdef ATTN_STAMP
+    ++ui;
+#endif
+  }
+#undef RSTAMP
+}
+
+template <int NTL>
+int launch_resident(const void* qkv, int64_t ldq, void* out, int64_t ldo, int B, int N, int H, float scale, float* lse,
+                    hipStream_t st) {
+  const int nunits = B * H;
+  const int ncu = vitm_cu_count();
+  const int grid = nunits < ncu ? nunits : ncu;
+  const float sl2e = scale * 1.4426950408889634f;
+  if (lse != nullptr) {
+    auto kfn = attn_resident_kernel<NTL, true>;
+    VITM_LDS_OPTIN(kfn, RES_SMEM, "vitm_attention_lse");
+    hipLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3(512), RES_SMEM, st, (const bf16_t*)qkv, ldq, (bf16_t*)out, ldo, N, H,
+                       sl2e, nunits, lse);
+  } else {
+    auto kfn = attn_resident_kernel<NTL, false>;
+    VITM_LDS_OPTIN(kfn, RES_SMEM, "vitm_attention");
+    hipLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3(512), RES_SMEM, st, (const bf16_t*)qkv, ldq, (bf16_t*)out, ldo, N, H,
+                       sl2e, nunits, lse);
+  }
+  VITM_CHECK_LAUNCH("vitm_attention (resident keys)");
+  return VITM_OK;
+}
+
 int launch_long(const void* qkv, int64_t ldq, void* out, int64_t ldo, int B, int N, int H, float scale, float* lse,
                 hipStream_t st) {
   const int last = N - (N - 1) / (32 * MAX_TILES) * (32 * MAX_TILES);   // keys of the last chunk, 1 .. 224
+#ifndef ATTN_NO_RESIDENT
+  if (N <= 32 * RES_MAX_TILES) {   // every K / V row of an (image, head) fits LDS
+    switch ((last + 31) / 32) {
+      case 1: return launch_resident<1>(qkv, ldq, out, ldo, B, N, H, scale, lse, st);
+      case 2: return launch_resident<2>(qkv, ldq, out, ldo, B, N, H, scale, lse, st);
+      case 3: return launch_resident<3>(qkv, ldq, out, ldo, B, N, H, scale, lse, st);
+      case 4: return launch_resident<4>(qkv, ldq, out, ldo, B, N, H, scale, lse, st);
+      case 5: return launch_resident<5>(qkv, ldq, out, ldo, B, N, H, scale, lse, st);
+      case 6: return launch_resident<6>(qkv, ldq, out, ldo, B, N, H, scale, lse, st);
+      default: return launch_resident<7>(qkv, ldq, out, ldo, B, N, H, scale, lse, st);
+    }
+  }
+#endif
   switch ((last + 31) / 32) {
     case 1: return launch_chunked<1>(qkv, ldq, out, ldo, B, N, H, scale, lse, st);
     case 2: return launch_chunked<2>(qkv, ldq, out, ldo, B, N, H, scale, lse, st);
