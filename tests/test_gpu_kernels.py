@@ -56,10 +56,12 @@ def test_gemm_bias(ops, M, N, K):
 @pytest.mark.parametrize("epi", ["bias", "ln", "ln_gelu", "resid", "bias_f32"])
 @pytest.mark.parametrize("M,N,K", [(8200, 2304, 768), (11111, 768, 3072), (9000, 1152, 384), (33000, 3072, 768),
                                    (16400, 520, 64), (50432, 768, 768), (50432, 3072, 768), (40000, 1024, 128),
-                                   (66000, 512, 256)])
+                                   (66000, 512, 256), (50432, 384, 384), (33333, 384, 1536), (40001, 320, 128),
+                                   (70000, 264, 64)])
 def test_gemm_big_tile_kernel(ops, M, N, K, epi):
-    """Shapes large enough to be routed to the 256x256 ping-pong kernel (ragged M and N tails included); the
-    last four leave a partly filled last round whose tiles are shared 3, 4, 2 and 4 ways between workgroups."""
+    """Shapes large enough to be routed to the 256x256 ping-pong kernel (ragged M and N tails included); shapes 5-9
+    leave a partly filled last round whose tiles are shared 3, 4, 2 and 4 ways between workgroups; the last four have a
+    second column tile at most 128 columns wide (N = 384: ViT-S/16), which runs as narrow tiles (128, 64 and 8 columns)."""
     A = _bf(_rand(M, K, seed=40) * 1.3 + 0.2)
     W, b = _rand(N, K, seed=41, scale=K ** -0.5), _rand(N, seed=42, scale=0.2)
     F = torch.nn.functional
@@ -90,7 +92,8 @@ def test_gemm_big_tile_kernel(ops, M, N, K, epi):
 
 
 @pytest.mark.parametrize("M,N,K,Kn", [(50432, 768, 768, 2304), (50432, 768, 3072, 3072), (33000, 1024, 256, 1024),
-                                      (40000, 384, 128, 1152), (66000, 512, 256, 512), (16400, 520, 64, 1040)])
+                                      (40000, 384, 128, 1152), (66000, 512, 256, 512), (16400, 520, 64, 1040),
+                                      (50432, 384, 1536, 1536), (33333, 384, 384, 1152)])
 def test_gemm_carried_layernorm_stats(ops, M, N, K, Kn):
     """The RESIDUAL epilogue's row moments (vitm_gemm_stats stats_out) against float64 moments of the stream it wrote,
     and an LN-folded GEMM fed with them (stats_partial) against the same GEMM fed by vitm_ln_stats.  Shapes cover

@@ -96,9 +96,10 @@ def test_gemm_small_tile_is_repeatable(ops, M, N, K, epi):
 
 
 @pytest.mark.parametrize("epi", ["ln", "ln_gelu", "bias", "resid_stats"])
-@pytest.mark.parametrize("M,N,K", [(9000, 1152, 384), (12608, 2304, 768), (16400, 1536, 384), (50432, 768, 768)])
+@pytest.mark.parametrize("M,N,K", [(9000, 1152, 384), (12608, 2304, 768), (16400, 1536, 384), (50432, 768, 768),
+                                   (50432, 384, 384), (33333, 384, 1536)])
 def test_gemm_big_tile_is_repeatable(ops, M, N, K, epi):
-    """The persistent 256x256-tile kernel, shared leftover tiles and carried moments included."""
+    """The persistent 256x256-tile kernel, shared leftover tiles, narrow last-column tiles and carried moments included."""
     A = (_rand(M, K, seed=11) * 1.2 + 0.1).to(torch.bfloat16)
     W, b = _rand(N, K, seed=12, scale=K ** -0.5), _rand(N, seed=13, scale=0.5)
     if epi.startswith("ln"):

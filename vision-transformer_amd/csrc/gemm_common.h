@@ -26,6 +26,7 @@ struct GemmArgs {
   // VITM_STATS_PARTS slots are summed; unused ones must be zero) and form mean / rstd over ln_dim values themselves.
   float* stats_out;
   int stats_partial;
+  int stats_last;      // the column tile whose epilogue also zero-fills the unused slots of stats_out (the real last one)
   float ln_inv_dim, ln_eps;
   // im2col source (patch embedding).  Big-tile kernel: img != nullptr selects the gathering loader; rows are
   // (image, token) with `cls` leading class-token slots per image, pw = 1 << pw_shift
@@ -82,7 +83,7 @@ struct EpiCols {
       // to lose the product of its LOW half in lanes 48..63 now and then (the output came out as c[n] bit for bit, with
       // every operand register correct when read back afterwards) whenever a second workgroup of this kernel shared the
       // CU: 100 .. 400 wrong elements per launch at M = 6304, N = 1152, K = 384, none with one workgroup per CU, none
-      // with the unpacked instruction (tests/test_gpu_kernels.py::test_gemm_small_tile_is_repeatable).
+      // with the unpacked instruction (tests/test_gpu_repeatable.py::test_gemm_small_tile_is_repeatable).
       const float nmean = -st.x;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {

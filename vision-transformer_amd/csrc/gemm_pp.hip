@@ -40,6 +40,15 @@
 // and has NBLK x 4 MFMAs per segment; every output element is still produced by exactly one wave with the same
 // K order, so results are bit-identical to the unshared schedule and need no workspace.
 //
+// Narrow last column tile.  N = 384 (ViT-S/16) is one and a half column tiles: computed as a 256-column tile, every
+// second tile of the proj / fc2 GEMMs spends half of its MFMAs, operand bytes and stores on columns that do not exist
+// (394 tiles = two full rounds of the chip for 1.15 rounds of work).  When N leaves at most 128 columns in the last of
+// two column tiles, the launch runs the whole tiles first and then, in the same kernel, a NARROW pass over the last
+// column: the 8 waves tile 256 rows x 128 columns as 4 row groups x 2 column waves (wave (g, c): rows 128 g + 64 (c >> 1),
+// columns 64 (c & 1); 4 row blocks = 16 MFMAs per segment, same segment schedule), only 128 weight rows are moved, and
+// the narrow tiles are dealt to the workgroups in reverse order, so that whoever got the fewest whole tiles gets the
+// narrow ones first.
+//
 // Epilogue, in registers only.  The weight tile is the MFMA A operand, so a lane holds 4 consecutive output
 // COLUMNS of one output row per accumulator tile; bias / folded-LayerNorm fix-up / GELU / LayerScale run on the
 // fp32 accumulators in place, v_permlane16_swap pairs the quads of two neighbouring column tiles into 8
@@ -176,21 +185,26 @@ __host__ __device__ inline Deal deal_tiles(int T, int nwg, int xg, bool share, i
 // NCHW bf16 image batch p.img and the DMA gathers it: a lane's 16-byte chunk is 8 consecutive pixels of one patch row
 // (patch width a power of two >= 8, so a chunk never straddles patch rows and the pixel column of a lane is the same in
 // every K-tile); from one K-tile to the next a lane moves down 64 / pw image rows, wrapping into the next channel.
-template <int EPI, int NBLK, bool SLICE, bool STATS = false, bool IM2COL = false>
+// NARROW (NBLK = 4, not SLICE): the pass over the last, at most 128 columns wide, column tile (see the head of the file).
+template <int EPI, int NBLK, bool SLICE, bool STATS = false, bool IM2COL = false, bool NARROW = false>
 __device__ __forceinline__ void tile_loop(const GemmArgs& p, char* smem) {
+  static_assert(!NARROW || (NBLK == 4 && !SLICE && !IM2COL), "narrow tiles: 4 row blocks per wave, whole tiles only");
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int grp = wave >> 2, wc = wave & 3;
+  const int wcol = NARROW ? (wc & 1) : wc;   // which 64-column slab of the tile this wave computes
 
   // ---- this workgroup's tiles.  Blocks b and b+8 share an XCD (and its L2): XCD group x = b & 7 takes a
   // contiguous run of row-major tiles and its workgroups walk that run side by side, so at any time the 32 tiles
   // in flight on an XCD share a few A row panels and W column panels.
-  const int T = p.tilesM * p.tilesN;
-  const int xg = blockIdx.x & 7, lg = blockIdx.x >> 3;
+  const int T = NARROW ? p.tilesM : p.tilesM * p.tilesN;   // NARROW: one tile per row panel, all in the last column
+  const int xg = blockIdx.x & 7;
   const Deal d = deal_tiles(T, p.ncu, xg, p.share != 0, p.S);
+  const int lg = NARROW ? d.wpx - 1 - (int)(blockIdx.x >> 3) : (int)(blockIdx.x >> 3);   // NARROW: dealt in reverse
   int ntl;
-  int i0 = 0, is0 = 0, is1 = 8;   // SLICE: first block computed; blocks [is0, is1) are the ones this slice owns and stores
+  int i0 = NARROW ? 4 * (wc >> 1) : 0;   // first 16-row block this wave computes (SLICE: of both wave groups alike)
+  int is0 = 0, is1 = 8;                  // SLICE: blocks [is0, is1) are the ones this slice owns and stores
   int lo_tile = -1;
   if (!SLICE) {
     ntl = d.full;
@@ -217,6 +231,11 @@ __device__ __forceinline__ void tile_loop(const GemmArgs& p, char* smem) {
   // rows of a band (band x 256 x K) fit an XCD's L2, so they are fetched once per XCD and band instead of once per
   // A row panel; the A panels are read once per band.
   auto tile_mn = [&](int w, int& mt, int& nt) {   // unsigned: the divisions by run-time values are half as long
+    if constexpr (NARROW) {
+      mt = w;
+      nt = p.tilesN - 1;
+      return;
+    }
     const unsigned per_band = (unsigned)p.tilesM * (unsigned)p.band;
     const unsigned b = (unsigned)w / per_band, r = (unsigned)w - b * per_band;
     unsigned bw = (unsigned)p.tilesN - b * (unsigned)p.band;
@@ -381,8 +400,10 @@ __device__ __forceinline__ void tile_loop(const GemmArgs& p, char* smem) {
     if (w_it >= ntl) return;
     char* sb = smem + WBASE + w_slot * PART + 4 * wave * 1024;
     const char* wb = wbase + (size_t)w_t * (BK * 2);
+    if (!NARROW || wave < 4) {   // a narrow tile has 128 weight rows: waves 0-3 move them
 #pragma unroll
-    for (int q = 0; q < 4; ++q) glds16(wb + wob[q], sb + q * 1024);
+      for (int q = 0; q < 4; ++q) glds16(wb + wob[q], sb + q * 1024);
+    }
     w_slot ^= 1;
     if (++w_t == nk) {
       w_t = 0;
@@ -396,7 +417,7 @@ __device__ __forceinline__ void tile_loop(const GemmArgs& p, char* smem) {
   for (int kk = 0; kk < 2; ++kk) {
     const int pch = ((kk * 4 + (lane >> 4)) ^ (lane & 7)) * 16;
     offA[kk] = (grp * 128 + i0 * 16 + (lane & 15)) * 128 + pch;
-    offB[kk] = WBASE + (wc * 64 + (lane & 15)) * 128 + pch;
+    offB[kk] = WBASE + (wcol * 64 + (lane & 15)) * 128 + pch;
   }
   int ca = 0, cw = 0;  // ring slots of the K-tile being consumed
 
@@ -489,8 +510,8 @@ __device__ __forceinline__ void tile_loop(const GemmArgs& p, char* smem) {
     const bool hi8 = (lane & 8) != 0;
     const int mrow = m0 + grp * 128 + i0 * 16 + (lane & 15);  // + 16 i  (accumulator layout)
     const int mst = m0 + grp * 128 + i0 * 16 + (lane & 7);    // + 16 i (+ 8 for the second store)
-    const int ncol = n0 + wc * 64 + 4 * q4;                   // + 16 j   (accumulator layout)
-    const int nsw = n0 + wc * 64 + ((q4 & 1) ? 16 + 4 * (q4 - 1) : 4 * q4);   // + 32 jp: columns held after the swap
+    const int ncol = n0 + wcol * 64 + 4 * q4;                 // + 16 j   (accumulator layout)
+    const int nsw = n0 + wcol * 64 + ((q4 & 1) ? 16 + 4 * (q4 - 1) : 4 * q4);   // + 32 jp: columns held after the swap
     const int nst = nsw + (hi8 ? 32 : 0);                                       // columns stored after the row-pair exchange
     float4 cq[4], sq[4], gq[4];
 #pragma unroll
@@ -545,7 +566,7 @@ __device__ __forceinline__ void tile_loop(const GemmArgs& p, char* smem) {
       if (grp == 1) __builtin_amdgcn_s_setprio(2);
       // a tile with no ragged edge stores without per-lane tests, from one pointer advanced by 16 rows per block (the
       // general path costs every block ~14 VALU instructions of address arithmetic and compares and four branches)
-      const bool fast = !SLICE && stores_on && m0 + BM <= p.M && n0 + BN <= p.N && (!IM2COL || p.cls == 0);
+      const bool fast = !SLICE && stores_on && m0 + BM <= p.M && n0 + (NARROW ? 128 : BN) <= p.N && (!IM2COL || p.cls == 0);
       // The exchanges above leave lane l with row (l & 7) and 16-byte chunk CH(l >> 3) of the wave's 128-byte rows.  Stored
       // like that, the 8 lanes of a row are 8 lanes apart, and the memory path takes 3.5 x as long over the instruction as
       // when consecutive lanes write consecutive chunks (8.7 k against 2.5 k cycles per 128-KiB tile on a CU by itself).
@@ -554,7 +575,7 @@ __device__ __forceinline__ void tile_loop(const GemmArgs& p, char* smem) {
       // Not where the GELU keeps the VALU busier than the stores keep the memory path (the stores hide behind it).
       constexpr bool TURN = EPI == VITM_EPI_BIAS || EPI == VITM_EPI_LN;
       const int xsrc = 4 * ((lane >> 3) + 8 * ((lane & 7) >> 2) + 16 * (((lane & 1) << 1) | ((lane >> 1) & 1)));
-      bf16_t* ofast = TURN ? (bf16_t*)p.out + (int64_t)(m0 + grp * 128 + i0 * 16 + (lane >> 3)) * p.ldo + (n0 + wc * 64 + 8 * (lane & 7))
+      bf16_t* ofast = TURN ? (bf16_t*)p.out + (int64_t)(m0 + grp * 128 + i0 * 16 + (lane >> 3)) * p.ldo + (n0 + wcol * 64 + 8 * (lane & 7))
                            : (bf16_t*)p.out + (int64_t)mst * p.ldo + nst;
       auto turn = [&](unsigned x) { return TURN ? (unsigned)__builtin_amdgcn_ds_bpermute(xsrc, (int)x) : x; };
 #pragma unroll
@@ -619,7 +640,7 @@ __device__ __forceinline__ void tile_loop(const GemmArgs& p, char* smem) {
         for (int i = 0; i < 8; ++i) rs[i][0] = rs[i][1] = rq[i][0] = rq[i][1] = 0.f;
       }
       // full tiles: residual and output through one advancing pointer each, no per-lane tests (see the bias branch)
-      const bool fast = !SLICE && stores_on && m0 + BM <= p.M && n0 + BN <= p.N;
+      const bool fast = !SLICE && stores_on && m0 + BM <= p.M && n0 + (NARROW ? 128 : BN) <= p.N;
       // (no lane-grid turn here: with the residual read and the output written, the 8 cross-lane reads per 16-row block
       // cost more than the faster stores return: proj +3.6 %, fc2 +1.9 % in the kernel trace, A/B of the whole forward)
       const bf16_t* rfast = p.resid + (int64_t)mst * p.ldr + nst;
@@ -752,20 +773,24 @@ __device__ __forceinline__ void tile_loop(const GemmArgs& p, char* smem) {
         for (int j = 0; j < 2; ++j) {
           const int ib = 4 * j + 2 * ((lane >> 5) & 1) + ((lane >> 4) & 1);
           const int R = 16 * ib + (hi8 ? 8 : 0) + (lane & 7);
-          *(float2*)(sb + ((grp * 128 + R) * 4 + wc) * 8) = make_float2(cs[j], cq2[j]);
+          if constexpr (NARROW) {   // rows are absolute inside the wave group's half (this wave owns blocks i0 .. i0 + 3); two column waves
+            if (ib < NBLK) *(float2*)(sb + ((grp * 128 + i0 * 16 + R) * 4 + wcol) * 8) = make_float2(cs[j], cq2[j]);
+          } else {
+            *(float2*)(sb + ((grp * 128 + R) * 4 + wc) * 8) = make_float2(cs[j], cq2[j]);
+          }
         }
         wait_lds();
         seg_barrier();
         if (tid < 256) {
           const float4 u = *(const float4*)(sb + tid * 32), w = *(const float4*)(sb + tid * 32 + 16);
           const int R = tid & 127, ib = R >> 4;
-          const int m = m0 + (tid >> 7) * 128 + i0 * 16 + R;
-          if (ib < NBLK && m < p.M && (!SLICE || (i0 + ib >= is0 && i0 + ib < is1))) {
+          const int m = NARROW ? m0 + (tid >> 7) * 128 + R : m0 + (tid >> 7) * 128 + i0 * 16 + R;
+          if ((NARROW || ib < NBLK) && m < p.M && (!SLICE || (i0 + ib >= is0 && i0 + ib < is1))) {
             float2* so = (float2*)(p.stats_out + ((int64_t)m * VITM_STATS_PARTS + nt_) * 2);
-            *so = make_float2((u.x + u.z) + (w.x + w.z), (u.y + u.w) + (w.y + w.w));
+            *so = NARROW ? make_float2(u.x + u.z, u.y + u.w) : make_float2((u.x + u.z) + (w.x + w.z), (u.y + u.w) + (w.y + w.w));
             // the last column tile also clears the slots of the column tiles this shape does not have: the consumer adds
             // all VITM_STATS_PARTS slots, and the buffer then needs no clearing by whoever allocated it
-            if (nt_ == p.tilesN - 1)
+            if (nt_ == p.stats_last)
               for (int z = nt_ + 1; z < VITM_STATS_PARTS; ++z) so[z - nt_] = make_float2(0.f, 0.f);
           }
         }
@@ -794,6 +819,20 @@ __global__ __launch_bounds__(NT, 2) void gemm_pp_shared_kernel(const GemmArgs p)
   wait_lds();       // the LDS reads of the last whole tile (moments combine) are over before the ring is refilled
   seg_barrier();
   tile_loop<EPI, NBLK_S, true, STATS, IM2COL>(p, smem);
+}
+
+// Whole tiles of every column but the last, then the narrow last column (see the head of the file).
+template <int EPI, bool STATS = false, bool KDEEP = false>
+__global__ __launch_bounds__(NT, 2) void gemm_pp_narrow_kernel(const GemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  GemmArgs q = p;             // the whole-tile pass sees a matrix without the last column tile
+  q.tilesN = p.tilesN - 1;
+  q.N = q.tilesN * BN;
+  q.band = q.tilesN;
+  tile_loop<EPI, 8, false, STATS, false>(q, smem);
+  wait_lds();
+  seg_barrier();
+  tile_loop<EPI, 4, false, STATS, false, true>(p, smem);
 }
 
 template <int EPI, int NBLK_S, bool STATS = false, bool IM2COL = false, bool KDEEP = false>   // NBLK_S = 8: nothing shared
@@ -859,6 +898,23 @@ int launch(const GemmArgs& a, hipStream_t st) {
     if (S < 2) b.share = 0;
   }
   b.S = S;
+  b.stats_last = b.tilesN - 1;
+  // two column tiles of which the second is at most half full (N = 257 .. 384): whole tiles + narrow pass, nothing shared
+  const int nrest = a.N - (b.tilesN - 1) * BN;
+  if (b.tilesN == 2 && nrest <= 128 && b.img == nullptr && (grid & 7) == 0) {
+    b.share = 0;
+    b.S = 1;
+    auto go = [&](auto kfn) {
+      VITM_LDS_OPTIN(kfn, SMEM, "vitm_gemm");
+      hipLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3(NT), SMEM, st, b);
+      VITM_CHECK_LAUNCH("vitm_gemm (256x256 tile, narrow last column)");
+      return VITM_OK;
+    };
+    if constexpr (EPI == VITM_EPI_RESIDUAL) {
+      if (b.stats_out != nullptr) return a.K > 1024 ? go(gemm_pp_narrow_kernel<EPI, true, true>) : go(gemm_pp_narrow_kernel<EPI, true, false>);
+    }
+    return go(gemm_pp_narrow_kernel<EPI, false, false>);
+  }
   if (EPI == VITM_EPI_RESIDUAL && b.stats_out != nullptr) {
     constexpr int E = VITM_EPI_RESIDUAL;   // the only epilogue whose output feeds a LayerNorm
     if (a.K > 1024) return b.share ? launch_shared<E, true, false, true>(b, grid, S, st) : launch_one<E, 8, true, false, true>(b, grid, st);
