@@ -196,3 +196,33 @@ def test_parallel_block_state_dict_matches_reference_fixture():
                            parallel_block=True)
     assert all(isinstance(b, ParallelBlock) for b in vt.blocks) and vt.parallel_block
     assert "blocks.1.fused_proj_2.weight" in vt.state_dict()
+
+
+def test_bench_reports_counter_files_only_for_the_sources_they_were_collected_on(tmp_path, monkeypatch):
+    """bench.py's PMC figures come from committed files; a file collected on other kernel sources (another csrc digest)
+    or for another workload must be withheld, with the reason in the note."""
+    import importlib
+    import json
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    bench = importlib.import_module("bench")
+    (tmp_path / "vision-transformer_amd" / "csrc").mkdir(parents=True)
+    (tmp_path / "profiles").mkdir()
+    (tmp_path / "vision-transformer_amd" / "csrc" / "k.hip").write_text("// kernel v1\n")
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    digest = bench.csrc_digest()
+    rec = {"config": "vit_b16", "batch_per_gpu": 256, "commit": "abc1234", "csrc_sha256": digest, "hbm_bytes_per_launch": 123.0}
+    (tmp_path / "profiles" / "r3_fc1_traffic.json").write_text(json.dumps(rec))
+    val, note = bench.committed_counters("fc1", "vit_b16", 256)
+    assert val == 123.0 and "abc1234" in note
+    val, note = bench.committed_counters("fc1", "vit_s16", 256)          # other workload
+    assert val is None and "no committed" in note
+    (tmp_path / "vision-transformer_amd" / "csrc" / "k.hip").write_text("// kernel v2\n")   # sources moved on
+    val, note = bench.committed_counters("fc1", "vit_b16", 256)
+    assert val is None and "stale" in note
+    # the committed files of this repository carry the provenance fields
+    import glob
+    for path in glob.glob(os.path.join(root, "profiles", "r3_*traffic.json")):
+        t = json.load(open(path))
+        assert t.get("csrc_sha256") and "commit" in t, path
