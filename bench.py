@@ -256,6 +256,43 @@ def hipblaslt_calibration(dev, n=4096, iters=20):
     return 2.0 * n ** 3 / (e0.elapsed_time(e1) / iters * 1e-3) / 1e12
 
 
+def host_fed_rate(model, x, dev, args):
+    """Images/s when the images start in HOST memory (never the headline ``value``): 4 micro-batches of the benchmark
+    batch per pass through vitm_amd.sharding.HostFedInference (upload of micro-batch i + 1 under the compute of i), for
+    pinned fp32, pinned bf16 and pageable fp32 sources, next to the one-shot cost of an un-overlapped upload."""
+    import torch
+    from vitm_amd.sharding import HostFedInference
+    feeder = HostFedInference(model, dev, micro_batch=args.batch)
+    n_mb = 4
+    host32 = x.float().cpu().repeat(n_mb, 1, 1, 1)
+    res = {"micro_batch": args.batch, "images_per_pass": host32.shape[0],
+           "note": "uploads overlapped with compute on a second stream; not the headline value"}
+    for tag, src in (("pinned_f32", host32.pin_memory()), ("pinned_bf16", host32.to(torch.bfloat16).pin_memory()),
+                     ("pageable_f32", host32)):
+        feeder.run(src)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        passes = 3
+        for _ in range(passes):
+            out = feeder.run(src)
+        torch.cuda.synchronize()
+        res[tag + "_images_per_sec"] = round(passes * src.shape[0] / (time.perf_counter() - t0), 1)
+    # un-overlapped: upload everything, then compute
+    src = host32.to(torch.bfloat16).pin_memory()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    xd = src.to(dev, non_blocking=True)
+    torch.cuda.synchronize()
+    t_up = time.perf_counter() - t0
+    res["upload_GBps_pinned"] = round(src.numel() * 2 / t_up / 1e9, 1)
+    with torch.no_grad():
+        for i in range(n_mb):
+            out = model(xd[i * args.batch:(i + 1) * args.batch])
+    torch.cuda.synchronize()
+    res["serial_pinned_bf16_images_per_sec"] = round(src.shape[0] / (time.perf_counter() - t0), 1)
+    return res
+
+
 def selftest_launch(args, world, rank, dist):
     """Launcher rehearsal without a GPU (gloo): the same rank start-up, barriers, max-over-ranks and JSON path
     around a no-op step.  Used by the CPU tests."""
@@ -302,6 +339,8 @@ def main():
     ap.add_argument("--force-dist", action="store_true",
                     help="create the nccl process group even for one rank: rehearses the barrier / gather / max-over-ranks "
                          "path on RCCL with the one GPU at hand")
+    ap.add_argument("--from-host", action="store_true",
+                    help="also report the rate with the images starting in host memory (line['host_fed'])")
     ap.add_argument("--selftest-launch", action="store_true",
                     help="rehearse the multi-rank launch on CPU (gloo) around a no-op step; no GPU is touched")
     args = ap.parse_args()
@@ -460,6 +499,8 @@ def main():
         line["whole_forward"]["hbm_bytes_per_image_measured"] = wf
         line["whole_forward"]["hbm_bytes_per_image_source"] = wf_note
         line["whole_forward"]["hbm_bytes_per_image_algorithmic"] = ALGO_BYTES_PER_IMAGE.get(args.config)
+        if args.from_host:
+            line["host_fed"] = host_fed_rate(model, x, dev, args)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, sd, batch=64 if args.config == "vit_tiny_cifar" else 8)
     if dist is not None:

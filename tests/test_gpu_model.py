@@ -284,6 +284,27 @@ def test_batch_independence_and_determinism():
     assert torch.equal(full, halves)
 
 
+def test_host_fed_pipeline_is_bit_identical():
+    """HostFedInference (uploads on a second stream under the compute of the previous micro-batch) returns what the
+    plain forward returns on the same micro-batches: pageable fp32 source (staged through pinned memory, cast on the
+    device), pinned bf16 source (uploaded from where it is), a ragged last micro-batch, and two passes through one
+    instance (the buffers and events are reused)."""
+    from vitm_amd.sharding import HostFedInference
+    model, sd, cfg = build("vit_tiny_cifar", seed=5)
+    host = torch.from_numpy(W.make_input(cfg, 23, 77))
+    feeder = HostFedInference(model, "cuda", micro_batch=8)
+    with torch.no_grad():
+        want = torch.cat([model(host[i:i + 8].cuda().to(torch.bfloat16)) for i in range(0, 23, 8)])
+    for _ in range(2):
+        assert torch.equal(feeder.run(host), want)
+    pinned = host.to(torch.bfloat16).pin_memory()
+    assert torch.equal(feeder.run(pinned), want)
+    assert torch.equal(feeder.run(host[:5]), want[:5])
+    assert feeder.run(host[:0]) is None
+    with pytest.raises(ValueError):
+        feeder.run(host.cuda())
+
+
 # (configuration, fixture, depth, batch, shard): the benchmarked workloads.  `shard` is a batch small enough that its
 # GEMMs leave the 256x256-tile route (fewer than 128 tiles), so the comparison with the whole batch crosses kernels.
 FULL_SIZE = [("vit_b16", "vit_b16", None, 256, 32), ("vit_s16", "vit_s16", None, 256, 32),
