@@ -205,7 +205,9 @@ def test_linear_backward_bf16(T, M, N, K):
 
 
 @pytest.mark.parametrize("B,N,H,hd", [(2, 65, 3, 64), (1, 197, 2, 64), (2, 50, 2, 96), (1, 33, 2, 32), (1, 100, 1, 128),
-                                      (1, 300, 1, 64), (2, 1, 2, 64)])
+                                      (1, 300, 1, 64), (2, 1, 2, 64),
+                                      # the one-workgroup kernel at its limits: 7 and 8 whole tiles, one row into the eighth
+                                      (1, 224, 2, 32), (1, 225, 1, 64), (1, 256, 2, 64), (1, 257, 1, 64)])
 def test_attention_backward_bf16(T, B, N, H, hd):
     from vitm_amd import _ops
     D = H * hd
