@@ -314,8 +314,26 @@ int vitm_colsum(const void* a, int64_t lda, const void* b, int64_t ldb, int dtyp
                 int D, int nchunks, vitm_stream_t stream);
 
 /*
+ * out_a[d] = sum_m a[m, d] and out_b[d] = sum_m b[m, d] for two contiguous fp32 (rows, D) arrays (b / out_b may both
+ * be null), one launch, fixed
+ * summation order: reduces the dw / db partial sums of vitm_layernorm_bwd to the gradients of nn.LayerNorm's weight
+ * and bias (models.py:189,196,310,324 under loss.backward(), train.py:219).
+ */
+int vitm_colsum_pair(const float* a, const float* b, int rows, int D, float* out_a, float* out_b, vitm_stream_t stream);
+
+/*
+ * LayerScale gradient out of the weight gradient of the Linear in front of it (x + gamma * Linear(h), models.py:209-210,
+ * 138-139): on entry dw (N, K) / db (N, nullable together with bias) hold the Linear's gradients taken WITHOUT gamma; on
+ * return dgamma[n] = sum_k w[n,k] dw[n,k] + bias[n] db[n] (= sum_m dy[m,n] z[m,n], so the Linear's output z need not be
+ * kept) and dw, db are multiplied by gamma[n] in place: the true gradients.  round_bf16: w is rounded to bf16 first, as
+ * the bf16 forward multiplied by it.
+ */
+int vitm_layerscale_grads(const float* w, const float* bias, float* dw, float* db, const float* gamma, float* dgamma, int N,
+                          int K, int round_bf16, vitm_stream_t stream);
+
+/*
  * LayerNorm backward: dx[m,:] = (dx_add ? dx_add[m,:] : 0) + rstd * (g - mean(g) - xhat * mean(g * xhat)), g = dy * w;
- * dw_partial / db_partial are (nblocks, D) fp32 per-workgroup sums of dy * xhat / dy (reduce them with vitm_colsum);
+ * dw_partial / db_partial are (nblocks, D) fp32 per-workgroup sums of dy * xhat / dy (reduce them with vitm_colsum_pair);
  * x, dy, dx_add and dx are in `dtype`.  Backward of nn.LayerNorm (models.py:189,196,310,324).
  */
 int vitm_layernorm_bwd(const void* x, int64_t ldx, const void* dy, int64_t lddy, const float* w, float eps,

@@ -40,7 +40,7 @@ def test_colsum(T, M, D):
     assert torch.equal(T.colsum(a, M, D, b), T.colsum(a, M, D, b)), "deterministic"
 
 
-@pytest.mark.parametrize("M,D", [(7, 64), (300, 192), (2000, 768), (65, 1024)])
+@pytest.mark.parametrize("M,D", [(7, 64), (300, 192), (2000, 768), (65, 1024), (9001, 768), (13000, 1536)])   # the last two: several rows per wave
 def test_layernorm_bwd(T, M, D):
     x = (_rand(M, D, seed=4) * 2 + 0.5).double().requires_grad_(True)
     w = (1 + 0.2 * _rand(D, seed=5)).double().requires_grad_(True)
@@ -54,6 +54,25 @@ def test_layernorm_bwd(T, M, D):
     assert _rel(dw, w.grad) <= 1e-4 and _rel(db, b.grad) <= 1e-4
     T.layernorm_bwd(x.detach().float(), dy, w.detach().float(), 1e-5, M, D, dx)
     assert _rel(dx, x.grad) <= 1e-4
+
+
+@pytest.mark.parametrize("M,N,K,with_bias", [(300, 96, 200, True), (513, 768, 3072, True), (64, 40, 72, False)])
+def test_layerscale_grads_from_weight_gradient(T, M, N, K, with_bias):
+    """y = gamma * (h W^T + b): dgamma, dW and db out of the UNSCALED weight / bias gradients equal float64 autograd."""
+    h, dy = _rand(M, K, seed=51).double(), _rand(M, N, seed=52).double()
+    w = (0.1 * _rand(N, K, seed=53)).double().requires_grad_(True)
+    b = (0.1 * _rand(N, seed=54)).double().requires_grad_(True) if with_bias else None
+    g = (0.5 + _rand(N, seed=55).abs()).double().requires_grad_(True)
+    z = h @ w.t() + (b if with_bias else 0)
+    (g * z).backward(dy)
+    dw = (dy.t() @ h).float().contiguous()            # what the weight-gradient GEMM delivers without gamma
+    db = dy.sum(0).float().contiguous() if with_bias else None
+    dg = torch.empty(N, device=DEV)
+    T.layerscale_grads(w.detach().float(), b.detach().float() if with_bias else None, dw, db, g.detach().float(), dg,
+                       round_bf16=False)
+    assert _rel(dg, g.grad) <= 1e-5 and _rel(dw, w.grad) <= 1e-5
+    if with_bias:
+        assert _rel(db, b.grad) <= 1e-5
 
 
 def test_gelu_bwd(T):
@@ -161,8 +180,8 @@ def test_colsum_bf16(T):
     assert _rel(T.colsum(a, M, D), a.double().sum(0)) <= 1e-5
 
 
-def test_layernorm_bwd_bf16(T):
-    M, D = 500, 192
+@pytest.mark.parametrize("M,D", [(500, 192), (20011, 384), (50432, 768)])
+def test_layernorm_bwd_bf16(T, M, D):
     x = (_rand(M, D, seed=34) * 2 + 0.5).to(BF)
     dy, add = _rand(M, D, seed=35).to(BF), _rand(M, D, seed=36).to(BF)
     w = (1 + 0.2 * _rand(D, seed=37))
@@ -175,6 +194,9 @@ def test_layernorm_bwd_bf16(T):
     T.layernorm_bwd(x, dy, w, 1e-5, M, D, dx, dx_add=add, dw_out=dw, db_out=db)
     assert _rel(dx, x64.grad + add.double()) <= 1e-2
     assert _rel(dw, w64.grad) <= 1e-4 and _rel(db, b64.grad) <= 1e-4
+    dx2, dw2, db2 = torch.empty_like(dx), torch.empty_like(dw), torch.empty_like(db)
+    T.layernorm_bwd(x, dy, w, 1e-5, M, D, dx2, dx_add=add, dw_out=dw2, db_out=db2)
+    assert torch.equal(dx, dx2) and torch.equal(dw, dw2) and torch.equal(db, db2), "deterministic"
 
 
 def test_gelu_bwd_and_residual_scale_bf16(T):

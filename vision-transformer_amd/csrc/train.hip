@@ -40,6 +40,17 @@ __device__ __forceinline__ void st8(bf16_t* p, const float (&v)[8]) {
   w.x = pack_bf2(v[0], v[1]); w.y = pack_bf2(v[2], v[3]); w.z = pack_bf2(v[4], v[5]); w.w = pack_bf2(v[6], v[7]);
   *(uint4*)p = w;
 }
+// the same eight elements as they come from memory: requested early, converted when they are needed
+struct Raw8f { float4 a, b; };
+__device__ __forceinline__ Raw8f ldraw8(const float* p) { return Raw8f{*(const float4*)p, *(const float4*)(p + 4)}; }
+__device__ __forceinline__ u16x8_t ldraw8(const bf16_t* p) { return *(const u16x8_t*)p; }
+__device__ __forceinline__ void cvt8(const Raw8f& r, float (&v)[8]) {
+  v[0] = r.a.x; v[1] = r.a.y; v[2] = r.a.z; v[3] = r.a.w; v[4] = r.b.x; v[5] = r.b.y; v[6] = r.b.z; v[7] = r.b.w;
+}
+__device__ __forceinline__ void cvt8(const u16x8_t& r, float (&v)[8]) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = bf2f(r[e]);
+}
 template <typename T>
 inline bool vec_ok(const void* p, int64_t ld) {   // rows start 16-byte aligned
   return p == nullptr || ((((uintptr_t)p) & 15) == 0 && (ld * (int64_t)sizeof(T)) % 16 == 0);
@@ -133,6 +144,67 @@ __global__ __launch_bounds__(256) void colsum8_kernel(const T* __restrict__ a, i
   if (oc < D) {
     float t = ((sh[0][g][e] + sh[1][g][e]) + (sh[2][g][e] + sh[3][g][e])) + ((sh[4][g][e] + sh[5][g][e]) + (sh[6][g][e] + sh[7][g][e]));
     out[(int64_t)blockIdx.y * ldo + oc] = t;
+  }
+}
+
+// column sums of TWO fp32 [rows, D] arrays in one launch (the per-workgroup partial sums of a LayerNorm's dw and db):
+// workgroup = 16 columns x 64 row lanes, blockIdx.y picks the array; a thread sums rows rl, rl + 64, ... in that order,
+// the 64 row lanes are added pairwise in a fixed tree.
+__global__ __launch_bounds__(1024) void colsum_pair_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                           float* __restrict__ out_a, float* __restrict__ out_b, int rows,
+                                                           int D) {
+  __shared__ float sh[64][17];
+  const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int col = blockIdx.x * 16 + cl;
+  const float* src = blockIdx.y ? b : a;   // b == nullptr: launched with one array only
+  float s = 0.f;
+  if (col < D)
+    for (int m = rl; m < rows; m += 64) s += src[(int64_t)m * D + col];
+  sh[rl][cl] = s;
+  __syncthreads();
+  for (int h = 32; h > 0; h >>= 1) {
+    if (rl < h) sh[rl][cl] += sh[rl + h][cl];
+    __syncthreads();
+  }
+  if (rl == 0 && col < D) (blockIdx.y ? out_b : out_a)[col] = sh[0][cl];
+}
+
+// ---- LayerScale gradient out of the weight gradient of the Linear in front of it -----------------------------------
+// y = x + gamma * z, z = h W^T + b.  With dy the gradient at y:  dgamma[n] = sum_m dy[m, n] z[m, n]
+//   = sum_k W[n, k] (sum_m dy[m, n] h[m, k]) + b[n] sum_m dy[m, n] = sum_k W[n, k] dWraw[n, k] + b[n] dbraw[n],
+// where dWraw / dbraw are the Linear's gradients taken WITHOUT gamma; its true gradients are gamma[n] times those.  So z
+// never has to be stored or read again: one workgroup per output row n forms the dot product (W rounded to bf16 first
+// when the forward multiplied by the bf16 weight) and scales the row in place.
+__global__ __launch_bounds__(256) void layerscale_grads_kernel(const float* __restrict__ w, const float* __restrict__ bias,
+                                                               float* __restrict__ dw, float* __restrict__ db,
+                                                               const float* __restrict__ gamma, float* __restrict__ dgamma,
+                                                               int K, int round_bf16) {
+  __shared__ float sh[256];
+  const int n = blockIdx.x, t = threadIdx.x;
+  const float* wr = w + (int64_t)n * K;
+  float* dr = dw + (int64_t)n * K;
+  const float g = gamma[n];
+  float s = 0.f;
+  for (int k = t; k < K; k += 256) {
+    float wv = wr[k];
+    if (round_bf16) wv = bf2f(f2bf(wv));
+    const float d = dr[k];
+    s = fmaf(wv, d, s);
+    dr[k] = d * g;
+  }
+  sh[t] = s;
+  __syncthreads();
+  for (int h = 128; h > 0; h >>= 1) {
+    if (t < h) sh[t] += sh[t + h];
+    __syncthreads();
+  }
+  if (t == 0) {
+    float r = sh[0];
+    if (bias) {
+      r = fmaf(bias[n], db[n], r);   // the bias is added in fp32 in the GEMM epilogue: no rounding
+      db[n] *= g;
+    }
+    dgamma[n] = r;
   }
 }
 
@@ -235,7 +307,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
 }
 
 // Fast form: rows 16-byte aligned, NC = ceil(D / 512) chunks of 8 columns per lane (registers sized to the row), 16-byte
-// accesses, enough workgroups in flight to hide the row-to-row latency.
+// accesses.  The wave's next row (x, dy and dx_add) is requested before the current row's three reductions, so a row
+// costs its arithmetic, not two trips to memory.
 template <typename T, int NC>
 __global__ __launch_bounds__(256) void layernorm_bwd8_kernel(const T* __restrict__ x, int64_t ldx,
                                                              const T* __restrict__ dy, int64_t lddy,
@@ -257,15 +330,32 @@ __global__ __launch_bounds__(256) void layernorm_bwd8_kernel(const T* __restrict
     }
   }
   const float inv_d = 1.0f / (float)D;
-  for (int m = blockIdx.x * 4 + wave; m < M; m += gridDim.x * 4) {
+  decltype(ldraw8(x)) xr[NC], gr[NC], ar[NC];
+  auto request = [&](int m) {
+#pragma unroll
+    for (int t = 0; t < NC; ++t) {
+      const int c = (lane + 64 * t) * 8;
+      if (c < D) {
+        xr[t] = ldraw8(x + (int64_t)m * ldx + c);
+        gr[t] = ldraw8(dy + (int64_t)m * lddy + c);
+        if (dx_add) ar[t] = ldraw8(dx_add + (int64_t)m * ldadd + c);
+      }
+    }
+  };
+  const int step = gridDim.x * 4;
+  int m = blockIdx.x * 4 + wave;
+  if (m < M) request(m);
+  for (; m < M; m += step) {
     float xv[NC][8], gv[NC][8];
+    decltype(ldraw8(x)) ac[NC];
     float s = 0.f;
 #pragma unroll
     for (int t = 0; t < NC; ++t) {
       const int c = (lane + 64 * t) * 8;
       if (c < D) {
-        ld8(x + (int64_t)m * ldx + c, xv[t]);
-        ld8(dy + (int64_t)m * lddy + c, gv[t]);
+        cvt8(xr[t], xv[t]);
+        cvt8(gr[t], gv[t]);
+        ac[t] = ar[t];
       } else {
 #pragma unroll
         for (int e = 0; e < 8; ++e) xv[t][e] = gv[t][e] = 0.f;
@@ -273,6 +363,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd8_kernel(const T* __restrict
 #pragma unroll
       for (int e = 0; e < 8; ++e) s += xv[t][e];
     }
+    if (m + step < M) request(m + step);
     const float mean = wave_sum(s) * inv_d;
     float q = 0.f;
 #pragma unroll
@@ -307,7 +398,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd8_kernel(const T* __restrict
         for (int e = 0; e < 8; ++e) rr[e] = rstd * (gv[t][e] - c1 - xv[t][e] * c2);
         if (dx_add) {
           float av[8];
-          ld8(dx_add + (int64_t)m * ldadd + c, av);
+          cvt8(ac[t], av);
 #pragma unroll
           for (int e = 0; e < 8; ++e) rr[e] += av[e];
         }
@@ -665,6 +756,16 @@ extern "C" int vitm_colsum(const void* a, int64_t lda, const void* b, int64_t ld
   return VITM_OK;
 }
 
+extern "C" int vitm_colsum_pair(const float* a, const float* b, int rows, int D, float* out_a, float* out_b,
+                                vitm_stream_t stream) {
+  VITM_REQUIRE(a && out_a && (!b == !out_b), "vitm_colsum_pair: null pointer (b and out_b go together)");
+  VITM_REQUIRE(rows > 0 && D > 0 && (int64_t)((D + 15) / 16) < 65536, "vitm_colsum_pair: bad shape");
+  hipLaunchKernelGGL(colsum_pair_kernel, dim3((unsigned)((D + 15) / 16), b ? 2 : 1), dim3(1024), 0, (hipStream_t)stream, a, b, out_a,
+                     out_b, rows, D);
+  VITM_CHECK_LAUNCH("vitm_colsum_pair");
+  return VITM_OK;
+}
+
 extern "C" int vitm_layernorm_bwd(const void* x, int64_t ldx, const void* dy, int64_t lddy, const float* w, float eps,
                                   const void* dx_add, int64_t ldadd, void* dx, int64_t lddx, int dtype, float* dw_partial,
                                   float* db_partial, int nblocks, int M, int D, vitm_stream_t stream) {
@@ -735,6 +836,16 @@ extern "C" int vitm_residual_scale(const void* resid, int64_t ldr, const void* z
     else hipLaunchKernelGGL(residual_scale_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)resid, ldr, (const bf16_t*)z, ldz, gamma, (bf16_t*)out, ldo, M, D);
   }
   VITM_CHECK_LAUNCH("vitm_residual_scale");
+  return VITM_OK;
+}
+
+extern "C" int vitm_layerscale_grads(const float* w, const float* bias, float* dw, float* db, const float* gamma,
+                                     float* dgamma, int N, int K, int round_bf16, vitm_stream_t stream) {
+  VITM_REQUIRE(w && dw && gamma && dgamma && (!bias == !db), "vitm_layerscale_grads: null pointer (bias and db go together)");
+  VITM_REQUIRE(N > 0 && K > 0, "vitm_layerscale_grads: bad shape");
+  hipLaunchKernelGGL(layerscale_grads_kernel, dim3((unsigned)N), dim3(256), 0, (hipStream_t)stream, w, bias, dw, db, gamma,
+                     dgamma, K, round_bf16);
+  VITM_CHECK_LAUNCH("vitm_layerscale_grads");
   return VITM_OK;
 }
 

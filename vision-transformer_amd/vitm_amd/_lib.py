@@ -79,6 +79,8 @@ SIGNATURES = {
     "vitm_gemm_tn_workspace_floats": (c_int64, [c_int, c_int, c_int]),
     "vitm_transpose": (c_int, [c_void_p, c_int, c_int64, c_void_p, c_int, c_int64, c_int, c_int, c_int, c_void_p, c_void_p]),
     "vitm_colsum": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
+    "vitm_colsum_pair": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "vitm_layerscale_grads": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "vitm_layernorm_bwd": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_float, c_void_p, c_int64, c_void_p,
                                    c_int64, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "vitm_qk_norm_bwd": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p, c_float, c_void_p,

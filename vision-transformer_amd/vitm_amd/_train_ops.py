@@ -96,7 +96,7 @@ def colsum(a: torch.Tensor, M: int, D: int, b: Optional[torch.Tensor] = None, ou
     if nch > 1:
         part = torch.empty((nch, D), dtype=F32, device=a.device)
         _lib.check(lib.vitm_colsum(_p(a), a.stride(0), _p(b), ldb, dt, _p(part), D, M, D, nch, _stream()), "vitm_colsum")
-        _lib.check(lib.vitm_colsum(_p(part), D, None, 0, _lib.F32, _p(out), D, nch, D, 1, _stream()), "vitm_colsum")
+        _lib.check(lib.vitm_colsum_pair(_p(part), None, nch, D, _p(_f32(out)), None, _stream()), "vitm_colsum_pair")
     else:
         _lib.check(lib.vitm_colsum(_p(a), a.stride(0), _p(b), ldb, dt, _p(out), D, M, D, 1, _stream()), "vitm_colsum")
     return out
@@ -112,6 +112,10 @@ def layernorm_bwd(x, dy, w, eps, M, D, dx, dx_add=None, dw_out=None, db_out=None
         _p(x), x.stride(0), _p(dy), dy.stride(0), _p(_f32(w)), float(eps), _p(dx_add),
         0 if dx_add is None else dx_add.stride(0), _p(dx), dx.stride(0), dt, _p(dwp), _p(dbp), nb, M, D, _stream()),
         "vitm_layernorm_bwd")
+    if dw_out is not None and db_out is not None:
+        _lib.check(_lib.load().vitm_colsum_pair(_p(dwp), _p(dbp), nb, D, _p(_f32(dw_out)), _p(_f32(db_out)), _stream()),
+                   "vitm_colsum_pair")
+        return
     if dw_out is not None:
         colsum(dwp, nb, D, out=dw_out)
     if db_out is not None:
@@ -136,6 +140,17 @@ def qk_norm_bwd(qkv_pre, dqkv, M, H, hd, q_w, q_eps, k_w, k_eps, dqw_out, dqb_ou
 def gelu_bwd(pre, dh, dpre, M, D) -> None:
     _lib.check(_lib.load().vitm_gelu_bwd(_p(pre), pre.stride(0), _p(dh), dh.stride(0), _p(dpre), dpre.stride(0),
                                          _rm(pre, dh, dpre), M, D, _stream()), "vitm_gelu_bwd")
+
+
+def layerscale_grads(weight, bias, dw, db, gamma, dgamma, round_bf16: bool) -> None:
+    """dgamma of ``x + gamma * Linear(h)`` from the Linear's gradients taken without gamma (dw [N, K], db [N] or None, both
+    contiguous fp32), which are then multiplied by gamma in place."""
+    N, K = weight.shape
+    assert dw.is_contiguous() and dw.shape == (N, K) and (bias is None) == (db is None)
+    _lib.check(_lib.load().vitm_layerscale_grads(_p(_f32(weight.detach())), _p(None if bias is None else _f32(bias.detach())),
+                                                 _p(_f32(dw)), _p(None if db is None else _f32(db)), _p(_f32(gamma)),
+                                                 _p(_f32(dgamma)), N, K, 1 if round_bf16 else 0, _stream()),
+               "vitm_layerscale_grads")
 
 
 def residual_scale(resid, z, gamma, out, M, D) -> None:

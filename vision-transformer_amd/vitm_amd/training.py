@@ -137,10 +137,18 @@ def _block_forward(blk: Block, x: torch.Tensor, B: int, N: int) -> (torch.Tensor
     _ops.gemm(n1, _pk(attn.qkv.weight, attn.qkv.bias, cd), qkv, _ops.EPI_BIAS, M)
     o = _buf(M, D, dev, cd)
     _attention_forward(attn, qkv, o, B, N, "Attention", s)
-    z1 = torch.empty((M, _ops.round_up(D, 8)), dtype=cd, device=dev)
-    _ops.gemm(o, _pk(attn.proj.weight, attn.proj.bias, cd), z1, _ops.EPI_BIAS, M)
+    # bf16: bias + LayerScale + residual in the projection's epilogue; the branch output z is not kept, the backward gets
+    # the LayerScale gradient out of the projection's weight gradient (T.layerscale_grads).  fp32: z kept, separate pass.
+    fused_ls = cd == torch.bfloat16
     x1 = _buf(M, D, dev, cd)
-    T.residual_scale(x, z1, _ops.f32vec(blk.ls1.gamma), x1, M, D)
+    z1 = z2 = None
+    if fused_ls:
+        _ops.gemm(o, _ops.pack_linear(attn.proj.weight, attn.proj.bias, out_scale=blk.ls1.gamma, dtype=cd), x1,
+                  _ops.EPI_RESIDUAL, M, resid=x)
+    else:
+        z1 = torch.empty((M, _ops.round_up(D, 8)), dtype=cd, device=dev)
+        _ops.gemm(o, _pk(attn.proj.weight, attn.proj.bias, cd), z1, _ops.EPI_BIAS, M)
+        T.residual_scale(x, z1, _ops.f32vec(blk.ls1.gamma), x1, M, D)
     n2 = x1
     if ln2 is not None:
         n2 = _buf(M, D, dev, cd)
@@ -150,10 +158,14 @@ def _block_forward(blk: Block, x: torch.Tensor, B: int, N: int) -> (torch.Tensor
     _ops.gemm(n2, p1, pre, _ops.EPI_BIAS, M)
     h = _buf(M, hid, dev, cd)
     _ops.gelu(pre, h, M, _ops.round_up(hid, 8))
-    z2 = torch.empty((M, _ops.round_up(D, 8)), dtype=cd, device=dev)
-    _ops.gemm(h, _pk(mlp.linear_layer2.weight, mlp.linear_layer2.bias, cd), z2, _ops.EPI_BIAS, M)
     x2 = _buf(M, D, dev, cd)
-    T.residual_scale(x1, z2, _ops.f32vec(blk.ls2.gamma), x2, M, D)
+    if fused_ls:
+        _ops.gemm(h, _ops.pack_linear(mlp.linear_layer2.weight, mlp.linear_layer2.bias, out_scale=blk.ls2.gamma, dtype=cd),
+                  x2, _ops.EPI_RESIDUAL, M, resid=x1)
+    else:
+        z2 = torch.empty((M, _ops.round_up(D, 8)), dtype=cd, device=dev)
+        _ops.gemm(h, _pk(mlp.linear_layer2.weight, mlp.linear_layer2.bias, cd), z2, _ops.EPI_BIAS, M)
+        T.residual_scale(x1, z2, _ops.f32vec(blk.ls2.gamma), x2, M, D)
     s.update(n1=n1, n2=n2, z1=z1, x1=x1, pre=pre, h=h, z2=z2)   # HBM is plentiful: nothing is recomputed in the backward
     return x2, s
 
@@ -243,6 +255,20 @@ def _linear_backward(G: _Grads, lin: nn.Linear, dy: torch.Tensor, x_in: torch.Te
     return T.linear_dx(dy, lin.weight, M, out=dx_out, gelu_input=gelu_input, dy_scale=dy_scale) if need_dx else None
 
 
+def _scaled_linear_backward(G: _Grads, lin: nn.Linear, ls_gamma: nn.Parameter, dy: torch.Tensor, x_in: torch.Tensor, M: int,
+                            gelu_input: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """bf16 backward of ``y = resid + gamma * lin(x_in)`` given dy at y, without the Linear's output: the weight-gradient
+    GEMM runs without gamma, vitm_layerscale_grads turns its result into G[gamma] and the true G[weight] / G[bias], and
+    the input-gradient GEMM folds gamma into W^T.  Returns dx_in."""
+    N, K = lin.weight.shape
+    dw = G.buf(lin.weight, N, K)
+    db = G.buf(lin.bias) if lin.bias is not None else None
+    T.linear_dw(dy, x_in, M, N, K, out=dw, bias_out=db)
+    gam = _ops.f32vec(ls_gamma)
+    T.layerscale_grads(lin.weight, lin.bias, dw, db, gam, G.buf(ls_gamma), round_bf16=True)
+    return T.linear_dx(dy, lin.weight, M, gelu_input=gelu_input, dy_scale=gam)
+
+
 def _scaled(dx: torch.Tensor, gamma: torch.Tensor, M: int, D: int):
     """(dy, dy_scale) for the Linear in front of a LayerScale, given the gradient behind it: bf16 keeps dx and hands the
     scale to the GEMMs (folded into W^T and into the rows of dW); fp32 materialises dx * gamma."""
@@ -262,11 +288,11 @@ def _block_backward(G: _Grads, blk: Block, s: dict, dx2: torch.Tensor, B: int, N
     g1, g2 = _ops.f32vec(blk.ls1.gamma), _ops.f32vec(blk.ls2.gamma)
 
     # ---- MLP branch: x2 = x1 + g2 * z2, z2 = fc2(gelu(pre)), pre = fc1(LN2(x1))
-    T.colsum(dx2, M, D, s["z2"], out=G.buf(blk.ls2.gamma))
-    dz2, sc2 = _scaled(dx2, g2, M, D)
-    if cd == torch.bfloat16:      # GELU backward in the epilogue of the input-gradient GEMM
-        dpre = _linear_backward(G, mlp.linear_layer2, dz2, s["h"], M, dy_scale=sc2, gelu_input=s["pre"])
+    if cd == torch.bfloat16:      # GELU backward in the epilogue of the input-gradient GEMM; LayerScale from the dW
+        dpre = _scaled_linear_backward(G, mlp.linear_layer2, blk.ls2.gamma, dx2, s["h"], M, gelu_input=s["pre"])
     else:
+        T.colsum(dx2, M, D, s["z2"], out=G.buf(blk.ls2.gamma))
+        dz2, sc2 = _scaled(dx2, g2, M, D)
         dh = _linear_backward(G, mlp.linear_layer2, dz2, s["h"], M)
         dpre = dh                                         # in place: element-wise
         T.gelu_bwd(s["pre"], dh, dpre, M, hid)
@@ -278,9 +304,12 @@ def _block_backward(G: _Grads, blk: Block, s: dict, dx2: torch.Tensor, B: int, N
         _add(dx2, dn2, dx1, M, D)
 
     # ---- attention branch: x1 = x + g1 * z1, z1 = proj(attn(qkv)), qkv = Wqkv LN1(x)
-    T.colsum(dx1, M, D, s["z1"], out=G.buf(blk.ls1.gamma))
-    dz1, sc1 = _scaled(dx1, g1, M, D)
-    d_o = _linear_backward(G, attn.proj, dz1, s["o"], M, dy_scale=sc1)
+    if cd == torch.bfloat16:
+        d_o = _scaled_linear_backward(G, attn.proj, blk.ls1.gamma, dx1, s["o"], M)
+    else:
+        T.colsum(dx1, M, D, s["z1"], out=G.buf(blk.ls1.gamma))
+        dz1, sc1 = _scaled(dx1, g1, M, D)
+        d_o = _linear_backward(G, attn.proj, dz1, s["o"], M, dy_scale=sc1)
     dqkv = torch.empty((M, 3 * D), dtype=cd, device=dev)
     _attention_backward(G, attn, s, d_o, dqkv, B, N, "Attention")
     dn1 = _linear_backward(G, attn.qkv, dqkv, s["n1"], M)
