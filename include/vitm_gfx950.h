@@ -45,8 +45,11 @@ enum vitm_epilogue {
   VITM_EPI_LN = 2,        /* out = rstd[m] * (acc - mean[m] * s[n]) + c[n]    (LayerNorm folded) */
   VITM_EPI_LN_GELU = 3,   /* out = gelu_erf(rstd[m] * (acc - mean[m] * s[n]) + c[n])            */
   VITM_EPI_RESIDUAL = 4,  /* out = resid[m,n] + g[n] * acc + c[n]   (bias + LayerScale + residual) */
-  VITM_EPI_DGELU = 5      /* out = acc * gelu_erf'(resid[m,n]): the GELU backward fused into the input-gradient
+  VITM_EPI_DGELU = 5,     /* out = acc * gelu_erf'(resid[m,n]): the GELU backward fused into the input-gradient
                              GEMM of the Linear that follows it (training; resid = the GELU's input, c unused)  */
+  VITM_EPI_BIAS_GELU2 = 6 /* out = acc + c[n] AND resid[m,n] = gelu_erf(acc + c[n]): `resid` is a second OUTPUT here
+                             (bf16, leading dimension ldr, written), so the training forward keeps the pre-activation
+                             for the backward without a separate GELU pass (models.py:127-128)                 */
 };
 
 const char* vitm_version(void);

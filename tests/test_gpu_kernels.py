@@ -91,6 +91,31 @@ def test_gemm_big_tile_kernel(ops, M, N, K, epi):
         _close(out, ref, rel=1e-4 if epi == "bias_f32" else 1e-2, what=f"big {epi}")
 
 
+@pytest.mark.parametrize("M,N,K", [(300, 200, 128), (788, 3072, 768), (8200, 2304, 768), (50432, 3072, 768), (33333, 1536, 384),
+                                   (16400, 520, 64), (70000, 264, 64)])
+def test_gemm_two_outputs_pre_activation_and_gelu(ops, M, N, K):
+    """VITM_EPI_BIAS_GELU2 (the training forward's fc1): `out` = the EPI_BIAS result bit for bit, the second output its
+    GELU; on the 128x128 route (first two shapes) and the 256x256 route incl. ragged edges, shared leftover tiles and a
+    narrow last column tile.  Pad columns / rows outside (M, N) of both buffers stay untouched."""
+    A = _bf(_rand(M, K, seed=60) * 1.3 + 0.2)
+    W, b = _rand(N, K, seed=61, scale=K ** -0.5), _rand(N, seed=62, scale=0.2)
+    pk = ops.pack_linear(W, b)
+    ld = pk.npad + 8
+    want = torch.empty((M, pk.npad), dtype=torch.bfloat16, device=DEV)
+    ops.gemm(A, pk, want, ops.EPI_BIAS, M)
+    pre = torch.full((M + 1, ld), 7.0, dtype=torch.bfloat16, device=DEV)
+    act = torch.full((M + 1, ld), 7.0, dtype=torch.bfloat16, device=DEV)
+    ops.gemm(A, pk, pre, ops.EPI_BIAS_GELU2, M, resid=act)
+    assert torch.equal(pre[:M, :pk.npad], want), "pre-activation differs from the plain bias epilogue"
+    ref = torch.nn.functional.gelu(A.float() @ _bf(W).float().t() + b)
+    _close(act[:M, :N], ref, rel=1e-2, what="gelu output")
+    # one bf16 ulp around gelu(bf16 pre-activation): the GELU is taken from the fp32 value before rounding
+    near = torch.nn.functional.gelu(want.float())
+    assert ((act[:M, :pk.npad].float() - near).abs() <= 2.0 ** -7 * near.abs() + 1e-3).all()
+    for buf in (pre, act):
+        assert (buf[M] == 7.0).all() and (buf[:, pk.npad:] == 7.0).all(), "wrote outside the result"
+
+
 @pytest.mark.parametrize("M,N,K,Kn", [(50432, 768, 768, 2304), (50432, 768, 3072, 3072), (33000, 1024, 256, 1024),
                                       (40000, 384, 128, 1152), (66000, 512, 256, 512), (16400, 520, 64, 1040),
                                       (50432, 384, 1536, 1536), (33333, 384, 384, 1152)])

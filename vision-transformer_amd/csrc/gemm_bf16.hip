@@ -240,6 +240,7 @@ int dispatch(const GemmArgs& a, int epi, int out_f32, hipStream_t st) {
     case VITM_EPI_LN_GELU: return launch<VITM_EPI_LN_GELU, AMODE, 0>(a, st);
     case VITM_EPI_RESIDUAL: return launch<VITM_EPI_RESIDUAL, AMODE, 0>(a, st);
     case VITM_EPI_DGELU: return launch<VITM_EPI_DGELU, AMODE, 0>(a, st);
+    case VITM_EPI_BIAS_GELU2: return launch<VITM_EPI_BIAS_GELU2, AMODE, 0>(a, st);
     default: break;
   }
   vitm_set_error("vitm_gemm: unknown epilogue %d", epi);
@@ -274,6 +275,9 @@ static int gemm_impl(const void* A, int64_t lda, const void* Wp, int64_t ldw, vo
                "vitm_gemm: RESIDUAL epilogue needs resid (ldr >= N, multiple of 8) and g");
   VITM_REQUIRE(epilogue != VITM_EPI_DGELU || (resid && aligned16(resid) && ldr >= N && ldr % 8 == 0 && out_dtype == VITM_BF16),
                "vitm_gemm: DGELU epilogue needs resid (the GELU input, ldr >= N, multiple of 8) and bf16 output");
+  VITM_REQUIRE(epilogue != VITM_EPI_BIAS_GELU2 ||
+                   (resid && resid != out && aligned16(resid) && ldr >= N && ldr % 8 == 0 && out_dtype == VITM_BF16 && row_group == 0),
+               "vitm_gemm: BIAS_GELU2 epilogue needs resid (the second output, ldr >= N, multiple of 8), bf16 output, row_group 0");
   VITM_REQUIRE(row_group >= 0, "vitm_gemm: row_group must be >= 0");
   // the big-tile kernel addresses a tile's operand rows by 32-bit byte offsets from the tile's first row
   const bool big = row_group == 0 && out_dtype == VITM_BF16 && vitm_gemm_pp_wanted(M, N, K) && lda < (1 << 22) && ldw < (1 << 22);

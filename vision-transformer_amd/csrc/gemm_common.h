@@ -15,7 +15,7 @@ struct GemmArgs {
   const float* s;
   const float* c;
   const float* g;
-  const bf16_t* resid;
+  const bf16_t* resid;   // RESIDUAL / DGELU: input; BIAS_GELU2: the second output (written)
   int64_t ldr;
   int M, N, K, tilesM, tilesN, row_group;
   int ncu, share, S;   // big-tile kernel: persistent workgroups, leftover tiles shared (0/1) by S workgroups each
@@ -91,9 +91,27 @@ struct EpiCols {
         asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(t) : "v"(sv[e]), "v"(nmean), "v"(v[e]));
         asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(v[e]) : "v"(t), "v"(st.y), "v"(cv[e]));
       }
-    } else if (EPI == VITM_EPI_BIAS || EPI == VITM_EPI_BIAS_GELU) {
+    } else if (EPI == VITM_EPI_BIAS || EPI == VITM_EPI_BIAS_GELU || EPI == VITM_EPI_BIAS_GELU2) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] += cv[e];
+    }
+    if (EPI == VITM_EPI_BIAS_GELU2) {   // the pre-activation to `out`, its GELU (below) to the second output
+      uint4 o;
+      o.x = pack_bf2(v[0], v[1]);
+      o.y = pack_bf2(v[2], v[3]);
+      o.z = pack_bf2(v[4], v[5]);
+      o.w = pack_bf2(v[6], v[7]);
+      *(uint4*)((bf16_t*)p.out + (int64_t)m * p.ldo + n) = o;
+#pragma unroll
+      for (int e = 0; e < 8; e += 2) {
+        const f32x2_t gl = gelu_erf2((f32x2_t){v[e], v[e + 1]});
+        o.x = e == 0 ? pack_bf2(gl.x, gl.y) : o.x;
+        o.y = e == 2 ? pack_bf2(gl.x, gl.y) : o.y;
+        o.z = e == 4 ? pack_bf2(gl.x, gl.y) : o.z;
+        o.w = e == 6 ? pack_bf2(gl.x, gl.y) : o.w;
+      }
+      *(uint4*)(const_cast<bf16_t*>(p.resid) + (int64_t)m * p.ldr + n) = o;
+      return;
     }
     if (EPI == VITM_EPI_LN_GELU || EPI == VITM_EPI_BIAS_GELU) {
 #pragma unroll

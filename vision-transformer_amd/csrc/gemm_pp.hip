@@ -578,6 +578,7 @@ __device__ __forceinline__ void tile_loop(const GemmArgs& p, char* smem) {
       bf16_t* ofast = TURN ? (bf16_t*)p.out + (int64_t)(m0 + grp * 128 + i0 * 16 + (lane >> 3)) * p.ldo + (n0 + wcol * 64 + 8 * (lane & 7))
                            : (bf16_t*)p.out + (int64_t)mst * p.ldo + nst;
       auto turn = [&](unsigned x) { return TURN ? (unsigned)__builtin_amdgcn_ds_bpermute(xsrc, (int)x) : x; };
+      bf16_t* o2fast = EPI == VITM_EPI_BIAS_GELU2 ? const_cast<bf16_t*>(p.resid) + (int64_t)mst * p.ldr + nst : nullptr;
 #pragma unroll
       for (int i = 0; i < NBLK; ++i) {
         if (i == (3 * NBLK + 3) / 4 && grp == 1) __builtin_amdgcn_s_setprio(0);
@@ -624,6 +625,32 @@ __device__ __forceinline__ void tile_loop(const GemmArgs& p, char* smem) {
             const int ntok = p.npatch + 1;
             if (m1 < p.M && m1 % ntok != 0) store_out(o, a0, b0, c0, d0);
             if (m2 < p.M && m2 % ntok != 0) store_out(o + 8 * p.ldo, a1, b1, c1, d1);
+          }
+        }
+        if (EPI == VITM_EPI_BIAS_GELU2) {
+          // second output: the GELU of the same values, in the same lane layout, to p.resid
+          gelu_erf2_n<8>(v);
+          a0 = pack_bf2(v[0].x, v[0].y), b0 = pack_bf2(v[1].x, v[1].y);
+          c0 = pack_bf2(v[2].x, v[2].y), d0 = pack_bf2(v[3].x, v[3].y);
+          a1 = pack_bf2(v[4].x, v[4].y), b1 = pack_bf2(v[5].x, v[5].y);
+          c1 = pack_bf2(v[6].x, v[6].y), d1 = pack_bf2(v[7].x, v[7].y);
+          swap16(a0, c0);
+          swap16(b0, d0);
+          swap16(a1, c1);
+          swap16(b1, d1);
+          rowpair_exchange1(a0, a1, hi8);
+          rowpair_exchange1(b0, b1, hi8);
+          rowpair_exchange1(c0, c1, hi8);
+          rowpair_exchange1(d0, d1, hi8);
+          if (fast) {
+            store_out(o2fast, a0, b0, c0, d0);
+            store_out(o2fast + 8 * p.ldr, a1, b1, c1, d1);
+            o2fast += 16 * p.ldr;
+          } else if (stores_on && nst < p.N && (!SLICE || (i0 + i >= is0 && i0 + i < is1))) {
+            const int m1 = mst + 16 * i, m2 = m1 + 8;
+            bf16_t* o2 = const_cast<bf16_t*>(p.resid) + (int64_t)m1 * p.ldr + nst;
+            if (m1 < p.M) store_out(o2, a0, b0, c0, d0);
+            if (m2 < p.M) store_out(o2 + 8 * p.ldr, a1, b1, c1, d1);
           }
         }
       }
@@ -943,6 +970,7 @@ int vitm_gemm_pp_launch(const GemmArgs& a, int epilogue, hipStream_t st) {
     case VITM_EPI_LN_GELU: return launch<VITM_EPI_LN_GELU>(a, st);
     case VITM_EPI_RESIDUAL: return launch<VITM_EPI_RESIDUAL>(a, st);
     case VITM_EPI_DGELU: return launch<VITM_EPI_DGELU>(a, st);
+    case VITM_EPI_BIAS_GELU2: return launch<VITM_EPI_BIAS_GELU2>(a, st);
     default: break;
   }
   vitm_set_error("vitm_gemm: unknown epilogue %d", epilogue);

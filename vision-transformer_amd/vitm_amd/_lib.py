@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get(
 BF16, F32 = 0, 1
 STATS_PARTS = 4   # VITM_STATS_PARTS
 ACT_GELU_ERF, ACT_RELU, ACT_GELU_TANH, ACT_SILU, ACT_SIGMOID, ACT_TANH = range(6)   # enum vitm_activation_kind
-EPI_BIAS, EPI_BIAS_GELU, EPI_LN, EPI_LN_GELU, EPI_RESIDUAL, EPI_DGELU = 0, 1, 2, 3, 4, 5
+EPI_BIAS, EPI_BIAS_GELU, EPI_LN, EPI_LN_GELU, EPI_RESIDUAL, EPI_DGELU, EPI_BIAS_GELU2 = 0, 1, 2, 3, 4, 5, 6
 
 
 class VitmLibraryError(RuntimeError):

@@ -10,7 +10,7 @@ from typing import Optional, Sequence
 import torch
 
 from . import _lib
-from ._lib import BF16, F32, EPI_BIAS, EPI_BIAS_GELU, EPI_LN, EPI_LN_GELU, EPI_RESIDUAL, EPI_DGELU  # noqa: F401
+from ._lib import BF16, F32, EPI_BIAS, EPI_BIAS_GELU, EPI_LN, EPI_LN_GELU, EPI_RESIDUAL, EPI_DGELU, EPI_BIAS_GELU2  # noqa: F401
 
 
 def round_up(a: int, b: int) -> int:

@@ -155,9 +155,12 @@ def _block_forward(blk: Block, x: torch.Tensor, B: int, N: int) -> (torch.Tensor
         _ops.layernorm(x1, n2, M, D, ln2[0], ln2[1], ln2[2])
     pre = _buf(M, hid, dev, cd)
     p1 = _pk(mlp.linear_layer1.weight, mlp.linear_layer1.bias, cd)
-    _ops.gemm(n2, p1, pre, _ops.EPI_BIAS, M)
     h = _buf(M, hid, dev, cd)
-    _ops.gelu(pre, h, M, _ops.round_up(hid, 8))
+    if cd == torch.bfloat16:      # one epilogue writes the pre-activation (kept for the backward) and its GELU
+        _ops.gemm(n2, p1, pre, _ops.EPI_BIAS_GELU2, M, resid=h)
+    else:
+        _ops.gemm(n2, p1, pre, _ops.EPI_BIAS, M)
+        _ops.gelu(pre, h, M, _ops.round_up(hid, 8))
     x2 = _buf(M, D, dev, cd)
     if fused_ls:
         _ops.gemm(h, _ops.pack_linear(mlp.linear_layer2.weight, mlp.linear_layer2.bias, out_scale=blk.ls2.gamma, dtype=cd),
@@ -339,9 +342,13 @@ def _pblock_forward(blk: ParallelBlock, x: torch.Tensor, B: int, N: int) -> (tor
     qkv = torch.empty((M, 3 * D), dtype=cd, device=dev)
     _ops.gemm(n, _pk(w1[:3 * D], b1[:3 * D] if b1 is not None else None, cd), qkv, _ops.EPI_BIAS, M)
     pre = _buf(M, hid, dev, cd)
-    _ops.gemm(n, _pk(w1[3 * D:], b1[3 * D:] if b1 is not None else None, cd), pre, _ops.EPI_BIAS, M)
     h = _buf(M, hid, dev, cd)
-    _ops.gelu(pre, h, M, _ops.round_up(hid, 8))
+    pk_mlp = _pk(w1[3 * D:], b1[3 * D:] if b1 is not None else None, cd)
+    if cd == torch.bfloat16:
+        _ops.gemm(n, pk_mlp, pre, _ops.EPI_BIAS_GELU2, M, resid=h)
+    else:
+        _ops.gemm(n, pk_mlp, pre, _ops.EPI_BIAS, M)
+        _ops.gelu(pre, h, M, _ops.round_up(hid, 8))
     o = _buf(M, D, dev, cd)
     _attention_forward(blk.attn, qkv, o, B, N, "ParallelBlockMultiHeadAttention", s)
     cat = _buf(M, 2 * D, dev, cd)                            # attention half | MLP half: the concat is free
