@@ -919,7 +919,8 @@ int launch_chunked(const void* qkv, int64_t ldq, void* out, int64_t ldo, int B, 
 // All 8 waves compute.  Q fragments come straight from global memory into registers (the next block's rows are requested
 // right after the last S phase of the current block, when the fragment registers fall free), and the output tile is
 // stored from registers as 32-byte segments (four instructions fill a row's 128-byte line).  Per unit: barrier, the 8
-// waves bring K and V by LDS-DMA (19 pieces each), barrier.  Within a block the softmax is the strip-wise one of the
+// waves bring K and V by LDS-DMA (19 pieces each) -- the first 224 keys first --, barrier when those are in, each wave's
+// first strip, barrier when the rest is in.  Within a block the softmax is the strip-wise one of the
 // chunked kernel: exact over 224 keys, a running maximum and one rescale of O per further 224.
 constexpr int RES_MAX_TILES = 19;
 constexpr int RES_OPB = RES_MAX_TILES * 32 * RS;      // K (or V) rows of one unit: 76 KiB
@@ -987,12 +988,17 @@ __global__ __launch_bounds__(512, 2) void attn_resident_kernel(const bf16_t* __r
     const bf16_t* base = qkv + (int64_t)b * N * ldq + h * HD;
     // ---- everyone is done with the previous unit's rows; K and V of this one, piece p by wave p & 7
     __builtin_amdgcn_s_barrier();
-    for (int pl = wave; pl < npieces; pl += 8) {
+    auto bring = [&](int pl) {
       int row = pl * 8 + lr;
       row = row < N ? row : N - 1;
       glds16(base + (int64_t)row * ldq + D + ((pl & 1) ? kcol1 : kcol0), lds0 + pl * 1024);
       glds16(base + (int64_t)row * ldq + 2 * D + vcol, lds0 + RES_OPB + pl * 1024);
-    }
+    };
+    // the first 224 keys (what the first strip of every wave's first block needs), then Q, then the rest: the first strip
+    // starts when the first part is in and runs under the arrival of the second
+    constexpr int P0 = 4 * MAX_TILES;   // pieces of the first strip
+    int pl = wave;
+    for (; pl < P0; pl += 8) bring(pl);
     // this wave's first Q fragments: row q0 + r, 16-byte chunk 2 s + hh
     int qb = wave;
     bf16x8_t qf[4];
@@ -1004,10 +1010,22 @@ __global__ __launch_bounds__(512, 2) void attn_resident_kernel(const bf16_t* __r
       for (int s = 0; s < 4; ++s) qf[s] = *(const bf16x8_t*)(qp + 16 * s);
     };
     if (qb < nqb) load_q(qb);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    int later = 0;   // DMA instructions of the second part issued by this wave
+    for (; pl < npieces; pl += 8, later += 2) bring(pl);
+    switch (later) {   // the counter takes an immediate
+      case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+      case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+      case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+      case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+      case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+      case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+      case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+      default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
     RSTAMP(1);
     __builtin_amdgcn_s_barrier();
     RSTAMP(2);
+    bool rest_pending = true;   // the second part has not been waited for yet (first strip of the wave's first block)
 
     for (; qb < nqb; qb += 8) {
       const int q0 = 32 * qb;
@@ -1114,6 +1132,11 @@ __global__ __launch_bounds__(512, 2) void attn_resident_kernel(const bf16_t* __r
 
       for (int c = 0; c + 1 < nchunks; ++c) {
         strip(std::integral_constant<int, MAX_TILES>{}, c * CK, CK, false);
+        if (rest_pending) {   // (every wave has a first block: 8 <= nqb; its first strip is a whole one: N > 224)
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();
+          rest_pending = false;
+        }
 #ifndef ATTN_NO_PREFETCH
         if (c == 0) {   // this wave's share of the next unit's lines: instructions pfi, pfi + 8, ... over its blocks
           const int blk_i = (qb - wave) >> 3;             // 0, 1, 2: which of this wave's blocks
