@@ -17,7 +17,7 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 WL="--config $CONFIG --batch $BATCH"
 BENCH="python3 bench.py $WL --steps 10 --warmup 3 --no-cpu-baseline"
-# counter passes: no long warm-up.  What was seen (round 2, no log kept): the --pmc passes run with the FULL bench command
+# counter passes: no long warm-up.  What was seen once (no log kept): the --pmc passes run with the FULL bench command
 # (~23 k dispatches, ~13 k of them queued by the 2-second warm-up before the first synchronize) did not finish inside
 # their 150-200 s limits, while the kernel-trace pass of the same command always finished in ~5 s.  With counters on the
 # profiler serialises every dispatch (the short command's ~1 k dispatches take a counter pass ~3 s, start-up included:
