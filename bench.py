@@ -183,12 +183,19 @@ def train_bench(args, world, rank, dist, dev):
             dist.barrier()
         torch.cuda.synchronize()
 
+    step = tr.step
+    if args.graph:       # the step replayed from a HIP graph (single process): two eager steps, one capture, then replays
+        from vitm_amd import GraphedTrainStep
+        if world > 1:
+            raise SystemExit("--graph with --mode train is single-process (the gradient all-reduce is not captured)")
+        step = GraphedTrainStep(tr, warmup=2).step
+        args.warmup = max(args.warmup, 4)
     for _ in range(args.warmup):
-        tr.step(x, y)
+        step(x, y)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss = tr.step(x, y)
+        loss = step(x, y)
     barrier()
     elapsed = max_over_ranks(time.perf_counter() - t0, dist, dev)
     assert torch.isfinite(loss).all()
@@ -203,7 +210,8 @@ def train_bench(args, world, rank, dist, dev):
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if bf16 else "f32", "data": "synthetic",
             "config": {"workload": f"{args.config}: forward + cross-entropy + backward + gradient all-reduce + clip + AdamW",
                        "batch_per_gpu": args.batch, "global_batch": args.batch * world,
-                       "parallelism": f"data parallel x{world}, one flat-gradient all-reduce (RCCL) per step"},
+                       "parallelism": f"data parallel x{world}, one flat-gradient all-reduce (RCCL) per step",
+                       "launch": "hip-graph replay" if args.graph else "eager (one host call per kernel)"},
             "roofline": {"bound": "mfma", "achieved": round(tf, 1), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(tf / peak, 4), "traffic": None,
                          "kernel": f"whole step against the dense {args.dtype} MFMA peak (3 x forward FLOPs)"},

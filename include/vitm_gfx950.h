@@ -398,6 +398,14 @@ int vitm_grad_clip_scratch_floats(void);
 int vitm_adamw_f32(float* p, const float* g, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
                    float beta2, float eps, float weight_decay, int step, vitm_stream_t stream);
 
+/*
+ * The same update with its scalars in DEVICE memory: hyper[7] = { lr, beta1, beta2, eps, weight_decay, 1 - beta1^step,
+ * sqrt(1 - beta2^step) }.  A launch captured into a HIP graph then follows the learning-rate schedule and the step count
+ * of train.py:223-224 (optimizer.step(); scheduler.step()) by rewriting those seven floats before each replay.
+ */
+int vitm_adamw_f32_hyper(float* p, const float* g, float* exp_avg, float* exp_avg_sq, int64_t n, const float* hyper,
+                         vitm_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -459,6 +459,35 @@ def test_checkpoint_round_trip_of_a_trainer(tmp_path):
         assert torch.equal(pa, pb), k
 
 
+@pytest.mark.parametrize("bf16", [False, True])
+def test_graphed_train_step_matches_the_eager_step(bf16):
+    """GraphedTrainStep (two eager steps, then one capture and replays; the AdamW scalars of the reference's warm-up /
+    cosine schedule rewritten in device memory before each replay) against Trainer.step on an identical model: same
+    losses, same gradient norms, same parameters and optimizer state after six steps, bit for bit."""
+    from vitm_amd import training, GraphedTrainStep
+    cfg = W.CONFIGS["tiny2"]
+    cd = torch.bfloat16 if bf16 else None
+    a, b = _model(cfg, 33), _model(cfg, 33)
+    opt_a, sched_a = training.reference_optimizer_and_scheduler(a, 1000)
+    opt_b, sched_b = training.reference_optimizer_and_scheduler(b, 1000)
+    tr_a = training.Trainer(a, opt_a, sched_a, max_norm=1.0, compute_dtype=cd)
+    tr_b = training.Trainer(b, opt_b, sched_b, max_norm=1.0, compute_dtype=cd)
+    g = GraphedTrainStep(tr_b, warmup=2)
+    for step in range(6):
+        x, y = _batch(cfg, 4, 500 + step)
+        la, lb = tr_a.step(x, y), g.step(x, y)
+        assert la.item() == lb.item(), f"loss of step {step}"
+        assert tr_a.last_grad_norm.item() == tr_b.last_grad_norm.item(), f"gradient norm of step {step}"
+        assert opt_a.param_groups[0]["lr"] == opt_b.param_groups[0]["lr"]
+    assert g.graph is not None and g.calls == 6
+    for (k, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):
+        assert torch.equal(pa, pb), k
+        assert torch.equal(opt_a.state[pa]["exp_avg_sq"], opt_b.state[pb]["exp_avg_sq"]), k
+        assert float(opt_a.state[pa]["step"]) == float(opt_b.state[pb]["step"]) == 6
+    with pytest.raises(RuntimeError):
+        g.step(*_batch(cfg, 2, 1))          # another batch shape than the captured one
+
+
 def test_flat_adamw_state_loads_into_torch_adamw_with_one_step_per_parameter():
     """The optimizer state a flat-mode Trainer saves must load into torch.optim.AdamW (the reference's optimizer) with
     a step counter per parameter: one shared counter would advance once per parameter per iteration there."""

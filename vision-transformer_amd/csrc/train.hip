@@ -713,6 +713,23 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
   }
 }
 
+// the same update with the seven scalars (lr, beta1, beta2, eps, weight decay, 1 - beta1^step, sqrt(1 - beta2^step)) read
+// from device memory: a captured launch then follows a learning-rate schedule without being captured again
+__global__ __launch_bounds__(256) void adamw_hyper_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                          float* __restrict__ v, int64_t n, const float* __restrict__ hyper) {
+  const float lr = hyper[0], beta1 = hyper[1], beta2 = hyper[2], eps = hyper[3], wd = hyper[4], bc1 = hyper[5], bc2_sqrt = hyper[6];
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float gi = g[i];
+    float pi = p[i] * (1.0f - lr * wd);
+    const float mi = fmaf(beta1, m[i], (1.0f - beta1) * gi);
+    const float vi = fmaf(beta2, v[i], (1.0f - beta2) * gi * gi);
+    m[i] = mi;
+    v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] = pi - (lr / bc1) * (mi / denom);
+  }
+}
+
 }  // namespace
 
 extern "C" int vitm_transpose(const void* src, int src_dtype, int64_t lds, void* dst, int dst_dtype, int64_t ldd, int M, int N,
@@ -942,5 +959,14 @@ extern "C" int vitm_adamw_f32(float* p, const float* g, float* exp_avg, float* e
   hipLaunchKernelGGL(adamw_kernel, dim3(stream_grid(n)), dim3(256), 0, (hipStream_t)stream, p, g, exp_avg, exp_avg_sq, n, lr, beta1,
                      beta2, eps, weight_decay, (float)bc1, (float)sqrt(bc2));
   VITM_CHECK_LAUNCH("vitm_adamw_f32");
+  return VITM_OK;
+}
+
+extern "C" int vitm_adamw_f32_hyper(float* p, const float* g, float* exp_avg, float* exp_avg_sq, int64_t n, const float* hyper,
+                                    vitm_stream_t stream) {
+  VITM_REQUIRE(p && g && exp_avg && exp_avg_sq && hyper, "vitm_adamw_f32_hyper: null pointer");
+  VITM_REQUIRE(n > 0, "vitm_adamw_f32_hyper: n must be positive");
+  hipLaunchKernelGGL(adamw_hyper_kernel, dim3(stream_grid(n)), dim3(256), 0, (hipStream_t)stream, p, g, exp_avg, exp_avg_sq, n, hyper);
+  VITM_CHECK_LAUNCH("vitm_adamw_f32_hyper");
   return VITM_OK;
 }

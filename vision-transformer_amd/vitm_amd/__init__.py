@@ -8,8 +8,8 @@ runs in hand-written HIP kernels behind the C ABI of ``include/vitm_gfx950.h``. 
 from . import models
 from .models import PatchEmbed, VisionTransformer, VITC, Attention
 from ._lib import VitmError, VitmLibraryError, version as library_version
-from .graph import GraphedForward
+from .graph import GraphedForward, GraphedTrainStep
 
 __all__ = ["models", "PatchEmbed", "VisionTransformer", "VITC", "Attention",
-           "VitmError", "VitmLibraryError", "library_version", "GraphedForward"]
+           "VitmError", "VitmLibraryError", "library_version", "GraphedForward", "GraphedTrainStep"]
 __version__ = "0.1.0"

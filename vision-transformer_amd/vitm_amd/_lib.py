@@ -94,6 +94,7 @@ SIGNATURES = {
     "vitm_grad_clip_scratch_floats": (c_int, []),
     "vitm_adamw_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float, c_float,
                                c_int, c_void_p]),
+    "vitm_adamw_f32_hyper": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     "vitm_cast_f32_to_bf16": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "vitm_cast_bf16_to_f32": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
 }

@@ -185,6 +185,22 @@ def adamw(p, g, m, v, lr, beta1, beta2, eps, wd, step) -> None:
                                           float(eps), float(wd), int(step), _stream()), "vitm_adamw_f32")
 
 
+def adamw_hyper_values(lr, beta1, beta2, eps, wd, step):
+    """The seven floats vitm_adamw_f32_hyper reads, formed as vitm_adamw_f32 forms them from its arguments (betas rounded
+    to fp32 first, bias corrections in double precision)."""
+    import struct
+    f32 = lambda x: struct.unpack("f", struct.pack("f", float(x)))[0]
+    b1, b2 = f32(beta1), f32(beta2)
+    return [float(lr), b1, b2, float(eps), float(wd), 1.0 - b1 ** int(step), (1.0 - b2 ** int(step)) ** 0.5]
+
+
+def adamw_hyper(p, g, m, v, hyper) -> None:
+    """AdamW update with (lr, beta1, beta2, eps, wd, 1 - beta1^t, sqrt(1 - beta2^t)) in the device tensor ``hyper``."""
+    assert hyper.dtype == torch.float32 and hyper.numel() >= 7 and hyper.is_cuda
+    _lib.check(_lib.load().vitm_adamw_f32_hyper(_p(p), _p(g), _p(m), _p(v), p.numel(), _p(hyper), _stream()),
+               "vitm_adamw_f32_hyper")
+
+
 # ---- Linear backward out of the forward GEMM ----------------------------------------------------------------------
 def linear_dx(dy: torch.Tensor, weight: torch.Tensor, M: int, out: Optional[torch.Tensor] = None,
               gelu_input: Optional[torch.Tensor] = None, dy_scale: Optional[torch.Tensor] = None) -> torch.Tensor:

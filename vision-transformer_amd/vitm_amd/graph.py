@@ -45,3 +45,55 @@ class GraphedForward:
             self.static_in.copy_(x, non_blocking=True)
         self.graph.replay()
         return self.static_out
+
+
+class GraphedTrainStep:
+    """``Trainer.step`` replayed from a HIP graph: ``g = GraphedTrainStep(trainer)`` then ``loss = g.step(images, labels)``.
+
+    A training step of this package is a fixed sequence of ~900 kernel launches for a fixed batch shape; at the
+    reference's own batch sizes (32 .. 64 CIFAR images, vitm/config/config.yaml) the launches, not the kernels, are the
+    step time.  The first ``warmup`` calls run ``trainer.step`` eagerly (real steps: they also opt the kernels into their
+    LDS sizes); the next call captures the kernels of a step and from then on every call is: write the seven AdamW scalars
+    for the current learning rate and step count to the device, copy the batch into the static input buffers, one graph
+    launch, ``scheduler.step()``.  The kernels and their order are those of the eager step.  Needs the flat AdamW of this
+    package, a single process (no gradient all-reduce) and batches of one shape; the returned loss is a copy.
+    """
+
+    def __init__(self, trainer, warmup: int = 2):
+        if trainer.params is None or trainer.reducer.active:
+            raise RuntimeError("GraphedTrainStep needs vitm_amd.training.AdamW in flat mode and a single process")
+        self.trainer, self.warmup, self.calls = trainer, max(1, int(warmup)), 0
+        self.graph = None
+
+    def _capture(self, images, labels):
+        tr = self.trainer
+        dev = images.device
+        self.x, self.y = images.detach().clone(), labels.detach().clone()
+        self.hyper = torch.zeros(8, dtype=torch.float32, device=dev)
+        torch.cuda.synchronize(dev)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.loss, self.norm = tr.device_step(self.x, self.y, self.hyper)
+
+    def step(self, images: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
+        tr = self.trainer
+        self.calls += 1
+        if self.calls <= self.warmup:
+            return tr.step(images, labels)
+        if self.graph is None:
+            self._capture(images, labels)
+        if images.shape != self.x.shape or images.dtype != self.x.dtype or labels.shape != self.y.shape:
+            raise RuntimeError(f"captured for images {tuple(self.x.shape)} {self.x.dtype}, got {tuple(images.shape)} {images.dtype}")
+        if not tr.optimizer._flat_ok():
+            raise RuntimeError("the parameters or gradients left the flat buffers the graph was captured on")
+        vals = tr.optimizer.next_hyper()
+        # a pageable source: the copy is staged at once, so the next call may overwrite nothing that is still to be read
+        self.hyper[:7].copy_(torch.tensor(vals, dtype=torch.float32))
+        self.x.copy_(images, non_blocking=True)
+        self.y.copy_(labels.to(self.y.dtype), non_blocking=True)
+        self.graph.replay()
+        tr.last_grad_norm = self.norm
+        if tr.scheduler is not None:
+            tr.scheduler.step()
+        return self.loss.clone()
+

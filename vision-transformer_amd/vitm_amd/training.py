@@ -733,20 +733,44 @@ class AdamW(torch.optim.Optimizer):
         if self._flat is not None:
             self._seed_flat_state()
 
-    def _flat_step(self) -> bool:
-        params, grads, m, v = self._flat
-        group = self.param_groups[0]
-        if not params.intact() or any(p.grad is None or p.grad.data_ptr() != grads.views[p].data_ptr() for p in params.params):
-            return False
+    def _flat_ok(self) -> bool:
+        params, grads, _, _ = self._flat
+        return params.intact() and all(p.grad is not None and p.grad.data_ptr() == grads.views[p].data_ptr() for p in params.params)
+
+    def _flat_advance(self) -> int:
+        """Host side of one flat update: every parameter's step counter moves on, cached packed weights are invalidated.
+        Returns the new step number."""
+        params = self._flat[0]
         for p in params.params:
             self.state[p]["step"] += 1
-        step = self.state[params.params[0]]["step"]
+            torch.autograd.graph.increment_version(p)       # cached packed weights must be rebuilt
+        return int(self.state[params.params[0]]["step"].item())
+
+    def _flat_step(self) -> bool:
+        if not self._flat_ok():
+            return False
+        params, grads, m, v = self._flat
+        group = self.param_groups[0]
+        step = self._flat_advance()
         b1, b2 = group["betas"]
         with torch.cuda.device(params.flat.device):
-            T.adamw(params.flat, grads.flat, m, v, group["lr"], b1, b2, group["eps"], group["weight_decay"], int(step.item()))
-        for p in params.params:
-            torch.autograd.graph.increment_version(p)       # cached packed weights must be rebuilt
+            T.adamw(params.flat, grads.flat, m, v, group["lr"], b1, b2, group["eps"], group["weight_decay"], step)
         return True
+
+    def flat_launch_from(self, hyper: torch.Tensor) -> None:
+        """Only the device side of a flat update, with its scalars read from ``hyper`` (7 fp32 on the device, see
+        ``next_hyper``): the launch a captured training step contains."""
+        params, grads, m, v = self._flat
+        with torch.cuda.device(params.flat.device):
+            T.adamw_hyper(params.flat, grads.flat, m, v, hyper)
+
+    def next_hyper(self):
+        """Advance the step counters (host side of a flat update) and return the seven scalars of that update for the
+        current learning rate."""
+        group = self.param_groups[0]
+        step = self._flat_advance()
+        b1, b2 = group["betas"]
+        return T.adamw_hyper_values(group["lr"], b1, b2, group["eps"], group["weight_decay"], step)
 
     def _unflatten_state(self) -> None:
         """Leave flat mode for good: the state entries get storage of their own and a step counter each."""
@@ -830,6 +854,25 @@ class Trainer:
                 dist.broadcast(t.data, src=src, group=self.group)
             for p in self.model.parameters():
                 torch.autograd.graph.increment_version(p)   # cached packed weights must be rebuilt
+
+    def device_step(self, images: torch.Tensor, labels: torch.Tensor, hyper: torch.Tensor):
+        """The kernels of a step and nothing else -- forward, loss, backward, clip, AdamW with its scalars from the device
+        tensor ``hyper`` -- for capture into a HIP graph (vitm_amd.graph.GraphedTrainStep does the host side around each
+        replay).  Single process, flat AdamW only.  Returns (loss, gradient norm), both device scalars."""
+        if self.params is None or self.reducer.active:
+            raise RuntimeError("device_step needs the flat AdamW of this package and no gradient all-reduce")
+        cd, _ = _check_trainable(self.model, images, self.compute_dtype)
+        with torch.no_grad(), torch.cuda.device(images.device):
+            self.grads.attach()
+            logits, S = forward_train(self.model, images, cd)
+            loss, dl = T.cross_entropy(logits, labels, want_grad=True)
+            G = backward_train(self.model, S, dl, sink=self.grads.views)
+            for p in self.grads.params:
+                if p not in G:
+                    self.grads.views[p].zero_()
+            norm = self.grads.clip_grad_norm_(self.max_norm)
+            self.optimizer.flat_launch_from(hyper)
+        return loss.reshape(()), norm
 
     def step(self, images: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
         """zero_grad, forward, loss, backward, all-reduce, clip, optimizer and scheduler step.  The backward kernels
