@@ -51,6 +51,13 @@ def provenance() -> dict:
     return {"commit": commit, "csrc_dirty_vs_commit": dirty, "csrc_sha256": csrc_digest()}
 
 
+def newest(pattern: str):
+    """The most recently written file matching ``pattern`` (a pass directory keeps the files of earlier collections: every
+    gpurun call merges its output into the local tree, named by the profiled process id), or None."""
+    files = glob.glob(pattern, recursive=True)
+    return max(files, key=os.path.getmtime) if files else None
+
+
 def short(name: str) -> str:
     name = name.replace("(anonymous namespace)::", "").replace("void ", "")
     name = re.sub(r"\(.*\)$", "", name)
@@ -66,10 +73,10 @@ def main(rnd: str, config: str = "vit_b16", batch: int = 256) -> None:
         rnd = f"{rnd}_{config}"
     prov = provenance()
     # ---- kernel stats
-    stats = glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True)
+    stats = newest(os.path.join(src, "trace", "**", "*kernel_stats.csv"))
     avg_ns = {}
     if stats:
-        rows = list(csv.DictReader(open(stats[0])))
+        rows = list(csv.DictReader(open(stats)))
         with open(os.path.join(out, f"{rnd}_kernel_stats.csv"), "w", newline="") as f:
             f.write(f"# rocprofv3 --kernel-trace --stats -- python3 bench.py {wl}--steps 10 --warmup 3 --no-cpu-baseline (MI355X); "
                     f"commit {prov['commit']}, csrc {prov['csrc_sha256']}\n")
@@ -82,19 +89,22 @@ def main(rnd: str, config: str = "vit_b16", batch: int = 256) -> None:
                             r["MinNs"], r["MaxNs"]])
     # ---- kernel stats of the training step (bench.py --mode train), when collected
     for tag, cmd in (("train_bf16", "--mode train --dtype bf16 --batch 256"), ("train_f32", "--mode train --dtype f32 --batch 64")):
-        tstats = glob.glob(os.path.join(src, tag, "**", "*kernel_stats.csv"), recursive=True)
+        tstats = newest(os.path.join(src, tag, "**", "*kernel_stats.csv"))
         if not tstats:
             continue
         with open(os.path.join(out, f"{rnd}_{tag}_kernel_stats.csv"), "w", newline="") as f:
             f.write(f"# rocprofv3 --kernel-trace --stats -- python3 bench.py {cmd} --steps 3 --warmup 1 (MI355X, ViT-B/16)\n")
             w = csv.writer(f)
             w.writerow(["kernel", "calls", "total_ns", "avg_ns", "percent", "min_ns", "max_ns"])
-            for r in csv.DictReader(open(tstats[0])):
+            for r in csv.DictReader(open(tstats)):
                 w.writerow([short(r["Name"]), r["Calls"], r["TotalDurationNs"], f"{float(r['AverageNs']):.0f}", r["Percentage"],
                             r["MinNs"], r["MaxNs"]])
     # ---- counters
     agg = collections.defaultdict(list)
-    for path in glob.glob(os.path.join(src, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
+    for passdir in sorted(glob.glob(os.path.join(src, "pmc_*"))):
+        path = newest(os.path.join(passdir, "**", "*counter_collection.csv"))
+        if path is None:
+            continue
         for r in csv.DictReader(open(path)):
             agg[(short(r["Kernel_Name"]), r["Counter_Name"])].append(float(r["Counter_Value"]))
     per = collections.defaultdict(dict)
