@@ -52,7 +52,7 @@ def _repeat(launch, ref=None, rel=1.5e-2, reps=REPS, what=""):
 SMALL_TILE = [(6304, 1152, 384), (6304, 768, 384), (4728, 1152, 768), (6304, 384, 1536), (5910, 1280, 384)]
 
 
-@pytest.mark.parametrize("epi", ["ln", "ln_gelu", "ln_f32", "bias", "bias_gelu", "resid"])
+@pytest.mark.parametrize("epi", ["ln", "ln_gelu", "ln_f32", "bias", "bias_gelu", "bias_gelu2", "resid"])
 @pytest.mark.parametrize("M,N,K", SMALL_TILE)
 def test_gemm_small_tile_is_repeatable(ops, M, N, K, epi):
     """The 128x128-tile kernel with 150-500 workgroups (one round of the chip, two workgroups per CU), every epilogue."""
@@ -90,12 +90,18 @@ def test_gemm_small_tile_is_repeatable(ops, M, N, K, epi):
         def launch():
             out = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
             return ops.gemm(A, pk, out, code, M)
+        if epi == "bias_gelu2":   # pre-activation and its GELU from one epilogue: both outputs must repeat
+            def launch():       # noqa: F811
+                out = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+                act = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+                ops.gemm(A, pk, out, ops.EPI_BIAS_GELU2, M, resid=act)
+                return out, act
     if epi != "ln_f32":   # an fp32 result never takes the big-tile route
         assert not ops.uses_big_tile(M, pk), "shape meant for the 128x128-tile kernel"
     _repeat(launch, ref, what=f"128x128 {epi} {M}x{N}x{K}")
 
 
-@pytest.mark.parametrize("epi", ["ln", "ln_gelu", "bias", "resid_stats"])
+@pytest.mark.parametrize("epi", ["ln", "ln_gelu", "bias", "bias_gelu2", "resid_stats"])
 @pytest.mark.parametrize("M,N,K", [(9000, 1152, 384), (12608, 2304, 768), (16400, 1536, 384), (50432, 768, 768),
                                    (50432, 384, 384), (33333, 384, 1536)])
 def test_gemm_big_tile_is_repeatable(ops, M, N, K, epi):
@@ -133,6 +139,10 @@ def test_gemm_big_tile_is_repeatable(ops, M, N, K, epi):
 
         def launch():
             out = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+            if epi == "bias_gelu2":
+                act = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+                ops.gemm(A, pk, out, ops.EPI_BIAS_GELU2, M, resid=act)
+                return out, act
             return ops.gemm(A, pk, out, ops.EPI_BIAS, M)
     assert ops.uses_big_tile(M, pk), "shape meant for the 256x256-tile kernel"
     _repeat(launch, ref, reps=8, what=f"256x256 {epi} {M}x{N}x{K}")
