@@ -354,10 +354,15 @@ def _pblock_forward(blk: ParallelBlock, x: torch.Tensor, B: int, N: int) -> (tor
     cat = _buf(M, 2 * D, dev, cd)                            # attention half | MLP half: the concat is free
     _ops.gemm(o, _pk(blk.attn.proj.weight, blk.attn.proj.bias, cd), cat[:, :D], _ops.EPI_BIAS, M)
     _ops.gemm(h, _pk(blk.mlp.out_proj.weight, blk.mlp.out_proj.bias, cd), cat[:, D:2 * D], _ops.EPI_BIAS, M)
-    z = torch.empty((M, D), dtype=cd, device=dev)
-    _ops.gemm(cat, _pk(blk.fused_proj_2.weight, blk.fused_proj_2.bias, cd), z, _ops.EPI_BIAS, M)
     x2 = _buf(M, D, dev, cd)
-    T.residual_scale(x, z, _ops.f32vec(blk.layer_scale.gamma), x2, M, D)
+    z = None
+    if cd == torch.bfloat16:      # bias + LayerScale + residual in the epilogue, z not kept (see _block_forward)
+        _ops.gemm(cat, _ops.pack_linear(blk.fused_proj_2.weight, blk.fused_proj_2.bias, out_scale=blk.layer_scale.gamma, dtype=cd),
+                  x2, _ops.EPI_RESIDUAL, M, resid=x)
+    else:
+        z = torch.empty((M, D), dtype=cd, device=dev)
+        _ops.gemm(cat, _pk(blk.fused_proj_2.weight, blk.fused_proj_2.bias, cd), z, _ops.EPI_BIAS, M)
+        T.residual_scale(x, z, _ops.f32vec(blk.layer_scale.gamma), x2, M, D)
     s.update(n=n, pre=pre, h=h, cat=cat, z=z)
     return x2, s
 
@@ -368,9 +373,12 @@ def _pblock_backward(G: _Grads, blk: ParallelBlock, s: dict, dx2: torch.Tensor, 
     ln = _ln(blk.norm, "ParallelBlock.norm")
     gam = _ops.f32vec(blk.layer_scale.gamma)
     # x2 = x + gamma * z, z = fused_proj_2(cat)
-    T.colsum(dx2, M, D, s["z"], out=G.buf(blk.layer_scale.gamma))
-    dz, sc = _scaled(dx2, gam, M, D)
-    dcat = _linear_backward(G, blk.fused_proj_2, dz, s["cat"], M, dy_scale=sc)    # [M, >= 2D]
+    if cd == torch.bfloat16:
+        dcat = _scaled_linear_backward(G, blk.fused_proj_2, blk.layer_scale.gamma, dx2, s["cat"], M)    # [M, >= 2D]
+    else:
+        T.colsum(dx2, M, D, s["z"], out=G.buf(blk.layer_scale.gamma))
+        dz, sc = _scaled(dx2, gam, M, D)
+        dcat = _linear_backward(G, blk.fused_proj_2, dz, s["cat"], M, dy_scale=sc)    # [M, >= 2D]
     # attention half: cat[:, :D] = attn.proj(o)
     d_o = _linear_backward(G, blk.attn.proj, dcat[:, :D], s["o"], M)
     # MLP half: cat[:, D:2D] = out_proj(gelu(pre))
