@@ -91,7 +91,8 @@ class HostFedInference:
     micro-batch i: two pinned staging buffers and two device buffers, a copy stream beside the compute stream, events
     between them.  The caller sees ``run(images) -> outputs`` with ``images`` a CPU tensor (N, C, H, W), fp32 or bf16;
     ``compute_dtype`` (default bf16) is what the replica computes in, and an fp32 upload is cast on the device.
-    Pinned, contiguous ``images`` are uploaded straight from where they are; pageable ones pass through the staging
+    Pinned, contiguous ``images`` are uploaded straight from where they are (leave them alone until the returned tensor
+    has been synchronised with); pageable ones pass through the staging
     buffers (a host memcpy per micro-batch, which then sets the pace: ~150 MB per 256 fp32 images of 224 x 224).
 
         feeder = HostFedInference(model, device, micro_batch=256)
@@ -113,12 +114,18 @@ class HostFedInference:
         self._ready = [torch.cuda.Event(), torch.cuda.Event()]     # upload into device buffer s finished
         self._free = [torch.cuda.Event(), torch.cuda.Event()]      # compute has consumed device buffer s
         self._staged = [torch.cuda.Event(), torch.cuda.Event()]    # pinned buffer s may be overwritten by the host
+        self._used = [False, False]                                # slot s has events recorded (kept across run() calls:
+                                                                   # the previous call's last uploads / forwards may still be in flight)
 
     def _buffers(self, like, rows: int, stage: bool) -> None:
         import torch
         shape = (rows,) + tuple(like.shape[1:])
         for s in range(2):
             if self._dev[s] is None or self._dev[s].shape != shape or self._dev[s].dtype != like.dtype:
+                if self._used[s]:                  # the old buffers may still be read: let their last users finish first
+                    self._staged[s].synchronize()
+                    self._free[s].synchronize()
+                    self._used[s] = False
                 self._dev[s] = torch.empty(shape, dtype=like.dtype, device=self.device)
                 self._pinned[s] = None
             if stage and self._pinned[s] is None:
@@ -135,7 +142,7 @@ class HostFedInference:
         pinned_src = images.is_pinned() and images.is_contiguous()   # upload straight from the caller's pinned memory
         self._buffers(images, mb, stage=not pinned_src)
         compute = torch.cuda.current_stream(self.device)
-        outs, used = [], [False, False]
+        outs, used = [], self._used
         with torch.no_grad():
             for i, lo in enumerate(range(0, n, mb)):
                 s, rows = i & 1, min(mb, n - lo)
