@@ -284,6 +284,49 @@ def test_batch_independence_and_determinism():
     assert torch.equal(full, halves)
 
 
+class _ConvEmbed(nn.Module):
+    """An embed_layer of the caller's own: the textbook strided convolution, in torch (the constructor signature is the
+    one the reference's VisionTransformer calls, models.py:291-295)."""
+
+    def __init__(self, image_size, patch_size, in_channels=3, embed_dim=768, **_):
+        super().__init__()
+        p = patch_size if isinstance(patch_size, int) else patch_size[0]
+        s = image_size if isinstance(image_size, int) else image_size[0]
+        self.num_patches = (s // p) ** 2
+        self.proj = nn.Conv2d(in_channels, embed_dim, p, p, bias=False)
+
+    def forward(self, x):
+        return self.proj(x).flatten(2).transpose(1, 2)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_foreign_embed_layer_runs_in_front_of_the_hip_blocks(dtype):
+    """VisionTransformer(embed_layer=<another class>): the foreign layer's forward makes the tokens, class token,
+    position embedding, blocks, final norm and head run here.  With the same projection weights the result equals the
+    model built on this package's PatchEmbed (fp32: 1e-4; bf16: the embedding rows at cosine >= 0.999)."""
+    from vitm_amd.models import VisionTransformer, VITC
+    cfg = W.CONFIGS["vit_tiny_cifar"]          # no norm layer inside the patch embedding
+    ref, sd, _ = build("vit_tiny_cifar", seed=4, depth=2, dtype=dtype)
+    vt = VisionTransformer(cfg["image_size"], patch_size=cfg["patch_size"], num_classes=cfg["num_classes"],
+                           num_heads=cfg["num_heads"], mlp_ratio=cfg["mlp_ratio"], depth=2,
+                           embed_dim=cfg["embed_dim"], norm_layer=nn.LayerNorm, embed_layer=_ConvEmbed,
+                           final_norm_layer=nn.LayerNorm if cfg["final_norm"] else None)
+    m = VITC(vt).eval()
+    own = {k: v for k, v in sd.items() if not k.startswith("vit_model.patch_embed.")}
+    missing, unexpected = m.load_state_dict(own, strict=False)
+    assert all(k.startswith("vit_model.patch_embed.") for k in missing) and not unexpected
+    m.vit_model.patch_embed.proj.weight.data.copy_(sd["vit_model.patch_embed.projection.weight"])
+    m = m.to(device="cuda", dtype=dtype)
+    x = torch.from_numpy(W.make_input(cfg, 3, 11)).cuda().to(dtype)
+    with torch.no_grad():
+        want, got = ref(x), m(x)
+        ew, eg = ref.vit_model(x), m.vit_model(x)
+    if dtype == torch.float32:
+        assert rel_err(got, want) <= 1e-4 and rel_err(eg, ew) <= 1e-4
+    else:
+        assert cos_rows(eg.float().reshape(-1, eg.shape[-1]), ew.float().reshape(-1, ew.shape[-1])) >= COS_MIN
+
+
 def test_host_fed_pipeline_is_bit_identical():
     """HostFedInference (uploads on a second stream under the compute of the previous micro-batch) returns what the
     plain forward returns on the same micro-batches: pageable fp32 source (staged through pinned memory, cast on the

@@ -448,19 +448,37 @@ class VisionTransformer(nn.Module):
         """forward_features on the residual-stream buffer: returns (x2d [B*N, ld] in x's dtype, B, N, D).  ``stats``
         ([B*N, 2] fp32) also receives the LayerNorm statistics of the finished rows (eps ``stats_eps``)."""
         pe = self.patch_embed
-        if not isinstance(pe, PatchEmbed) or not pe.flatten:
-            raise NotImplementedError("the HIP path needs this package's PatchEmbed with flatten=True as embed_layer")
+        native = isinstance(pe, PatchEmbed)
+        if native and not pe.flatten:
+            raise NotImplementedError("VisionTransformer needs (B, N, D) tokens: PatchEmbed(flatten=True)")
         if self.pos_embed is None:
             raise TypeError("pos_embed is None: the reference adds it unconditionally (models.py:360)")
         B = x.shape[0]
-        D, Np = self.embed_dim, pe.num_patches
+        D = self.embed_dim
         has_cls = self.class_token is not None
+        tokens = None
+        if native:
+            Np = pe.num_patches
+        else:
+            # an embed_layer of the caller's own (the reference instantiates and calls whatever class it is given,
+            # models.py:275,352): its forward produces the tokens, everything behind it runs here
+            _ops.require_cuda(x, "VisionTransformer.forward")
+            tokens = pe(x)
+            if tokens.dim() != 3 or tokens.shape[0] != B or tokens.shape[2] != D:
+                raise RuntimeError(f"embed_layer returned {tuple(tokens.shape)}, expected (B, N, {D}) tokens")
+            Np = tokens.shape[1]
         N = Np + (1 if has_cls else 0)
+        if self.pos_embed.shape[-2] != N:
+            raise RuntimeError(f"pos_embed holds {self.pos_embed.shape[-2]} positions, the embedding produced {N} tokens")
         ld = _ops.round_up(D, _ops.k_multiple())
         alloc = torch.zeros if ld != D else torch.empty
         x2d = alloc((B * N, ld), dtype=_ops.compute_dtype(x), device=x.device)
-        pe._tokens_into(x, x2d, cls_slot=has_cls)
-        en = layernorm_params(pe.norm_layer, "PatchEmbed.norm_layer")
+        if native:
+            pe._tokens_into(x, x2d, cls_slot=has_cls)
+            en = layernorm_params(pe.norm_layer, "PatchEmbed.norm_layer")
+        else:
+            x2d.view(B, N, ld)[:, (1 if has_cls else 0):, :D].copy_(tokens)
+            en = None                     # whatever norm the foreign layer has is part of its forward
         npre = layernorm_params(self.norm_pre, "VisionTransformer.norm_pre")
         f = _ops.f32vec
         _ops.embed_finalize(
