@@ -244,6 +244,11 @@ def _attn_ref(qkv, B, N, H, hd):
 @pytest.mark.parametrize("B,N,H,hd", [(2, 197, 3, 64), (1, 65, 2, 64), (1, 577, 2, 64), (3, 32, 1, 64),
                                       (2, 1, 2, 64), (1, 65, 2, 96), (1, 197, 2, 32), (1, 100, 1, 128),
                                       (1, 300, 1, 64),
+                                      # both sides of the kernel boundaries at head dim 64 (224 | 225: one pair's keys in
+                                      # the ring | resident keys; 608 | 609: resident | chunked keys), longer sequences,
+                                      # and more (image, head) pairs than workgroups (several items per workgroup)
+                                      (1, 224, 2, 64), (1, 225, 2, 64), (1, 608, 1, 64), (1, 609, 1, 64), (1, 785, 2, 64),
+                                      (1, 1025, 1, 64), (30, 197, 12, 64), (25, 577, 12, 64), (12, 640, 12, 64),
                                       # head dims the kernels pad to the next multiple of 32 (80: ViT-H/14)
                                       (2, 257, 3, 80), (1, 65, 2, 48), (1, 197, 2, 8), (1, 50, 3, 40), (1, 130, 2, 104),
                                       (1, 70, 1, 120)])
