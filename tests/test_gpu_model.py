@@ -271,6 +271,39 @@ def test_head_dim_80_model_against_oracle(dtype):
         assert (logits - ref_logits).abs().max().item() <= logit_tol(ref_logits)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("image_size,patch,class_token", [((32, 64), 8, True), ((48, 32), 4, True), ((32, 64), 8, None)])
+def test_non_square_images_and_no_class_token(image_size, patch, class_token, dtype):
+    """image_size as an (H, W) pair (patch_embeddings.py:71-87) and class_token=None (models.py:298-303: any other value,
+    False included, still makes a class token) against the oracle on the module's own randomly initialised weights."""
+    from oracle import vit_oracle as O
+    from vitm_amd.models import VisionTransformer
+    torch.manual_seed(31)
+    LN = nn.LayerNorm
+    vt = VisionTransformer(image_size, patch_size=patch, num_classes=10, num_heads=4, mlp_ratio=2.0, depth=2, embed_dim=128,
+                           norm_layer=LN, embed_norm_layer=LN, final_norm_layer=LN, class_token=class_token).eval()
+    n_patches = (image_size[0] // patch) * (image_size[1] // patch)
+    assert (vt.class_token is None) == (class_token is None)
+    assert vt.pos_embed.shape[-2] == n_patches + (0 if class_token is None else 1)
+    with torch.no_grad():
+        for n, p in vt.named_parameters():      # the init leaves LayerScale at 1e-5 and biases at zero: make every term count
+            if n.endswith("gamma"):
+                p.fill_(0.5)
+            elif n.endswith("bias"):
+                p.normal_(0, 0.1)
+    sd = {k: v.detach().clone() for k, v in vt.state_dict().items()}
+    x = torch.randn(3, 3, *image_size)
+    want = O.vit_forward(x, sd, dict(image_size=image_size, patch_size=(patch, patch), num_heads=4, depth=2))
+    vt = vt.to(device="cuda", dtype=dtype)
+    with torch.no_grad():
+        got = vt(x.cuda().to(dtype)).float().cpu()
+    assert got.shape == want.shape == (3, vt.pos_embed.shape[-2], 128)
+    if dtype == torch.float32:
+        assert rel_err(got, want) <= 1e-4
+    else:
+        assert cos_rows(got, want) >= COS_MIN
+
+
 def test_batch_independence_and_determinism():
     """Images are independent: a batch equals its halves run separately (the multi-GPU sharding invariant),
     and two runs are bit-identical."""
