@@ -304,6 +304,30 @@ def test_non_square_images_and_no_class_token(image_size, patch, class_token, dt
         assert cos_rows(got, want) >= COS_MIN
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_empty_batch_gives_empty_results(dtype):
+    """A batch of zero images (the tail of a sharded data set) returns tensors of the right shape and dtype from every
+    module, as the reference's torch modules do; the shape checks of the embedding still apply."""
+    from vitm_amd.models import PatchEmbed
+    model, sd, cfg = build("vit_tiny_cifar", seed=5, dtype=dtype)
+    vt = model.vit_model
+    D, N = cfg["embed_dim"], vt.patch_embed.num_patches + 1
+    x = torch.zeros((0, 3, 32, 32), device="cuda", dtype=dtype)
+    t = torch.zeros((0, N, D), device="cuda", dtype=dtype)
+    with torch.no_grad():
+        outs = {"VITC": (model(x), (0, cfg["num_classes"])), "VisionTransformer": (vt(x), (0, N, D)),
+                "forward_features": (vt.forward_features(x), (0, N, D)), "forward_heads": (vt.forward_heads(t), (0, N, D)),
+                "PatchEmbed": (vt.patch_embed(x), (0, N - 1, D)), "Block": (vt.blocks[0](t), (0, N, D)),
+                "Attention": (vt.blocks[0].attn(t), (0, N, D)), "MLP": (vt.blocks[0].mlp(t), (0, N, D)),
+                "LayerScale": (vt.blocks[0].ls1(t), (0, N, D))}
+        pe = PatchEmbed(image_size=32, patch_size=8, embed_dim=32, flatten=False).to(device="cuda", dtype=dtype)
+        outs["PatchEmbed(flatten=False)"] = (pe(x), (0, 32, 4, 4))
+        for name, (y, shape) in outs.items():
+            assert tuple(y.shape) == shape and y.dtype == dtype and y.is_cuda, (name, tuple(y.shape), y.dtype)
+        with pytest.raises(AssertionError):
+            model(torch.zeros((0, 3, 30, 30), device="cuda", dtype=dtype))
+
+
 def test_batch_independence_and_determinism():
     """Images are independent: a batch equals its halves run separately (the multi-GPU sharding invariant),
     and two runs are bit-identical."""

@@ -25,6 +25,9 @@ class VITC(nn.Module):
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         """(B, C, H, W) images -> (B, num_classes) logits, in the dtype of ``x``."""
         _ops.require_cuda(x, "VITC.forward")
+        if x.shape[0] == 0:                       # an empty batch is an empty result, as in the reference
+            self.vit_model._empty_tokens(x)       # (its shape checks)
+            return x.new_empty((0, self.head.out_features), dtype=_ops.compute_dtype(x))
         if (torch.is_grad_enabled() and x.dtype in (torch.float32, torch.bfloat16)
                 and any(p.requires_grad for p in self.parameters())):
             # training: the forward that keeps its activations, with a hand-written backward behind it (fp32 images:

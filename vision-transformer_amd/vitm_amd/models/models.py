@@ -132,6 +132,8 @@ class Attention(nn.Module):
         _ops.require_cuda(x, "Attention.forward")
         self._check()
         B, N, C = x.shape
+        if B * N == 0:                            # an empty batch (or no tokens) is an empty result, as in the reference
+            return x.new_empty((B, N, C), dtype=_ops.compute_dtype(x))
         with torch.cuda.device(x.device):
             xb, M = _as_rows(x, C)
             dt = xb.dtype
@@ -209,6 +211,8 @@ class MLP(nn.Module):
             lead = rows.shape[:-1]
         else:
             rows, lead = x, x.shape[:-1]
+        if x.numel() == 0:
+            return x.new_empty(x.shape, dtype=_ops.compute_dtype(x))
         with torch.cuda.device(x.device):
             xb, M = _as_rows(rows, C)
             dt = xb.dtype
@@ -237,6 +241,8 @@ class LayerScale(nn.Module):
         D = self.gamma.numel()
         if D % 8 != 0:
             raise NotImplementedError("LayerScale on the HIP path needs dim % 8 == 0")
+        if x.numel() == 0:
+            return x if self.inplace else x.new_empty(x.shape, dtype=_ops.compute_dtype(x))
         with torch.cuda.device(x.device):
             M = x.numel() // D
             g = _ops.f32vec(self.gamma)
@@ -355,6 +361,8 @@ class Block(nn.Module):
         B, N, D = x.shape
         if D != self.dim:
             raise RuntimeError(f"Block(dim={self.dim}) got an input with last dim {D}")
+        if B * N == 0:
+            return x.new_empty((B, N, D), dtype=_ops.compute_dtype(x))
         with torch.cuda.device(x.device):
             xb, M = _as_rows(x, D)
             if xb.data_ptr() == x.data_ptr():
@@ -518,9 +526,18 @@ class VisionTransformer(nn.Module):
         _ops.layernorm(x2d, out, B * N, D, _ops.f32vec(ln[0]), _ops.f32vec(ln[1]), ln[2])
         return out.reshape(B, N, D)
 
+    def _empty_tokens(self, x: torch.Tensor) -> torch.Tensor:
+        """The (0, N, D) result of an empty image batch (after the embedding layer's own shape checks)."""
+        pe = self.patch_embed
+        Np = pe(x).shape[1] if not isinstance(pe, PatchEmbed) else (pe._check_image(x), pe.num_patches)[1]
+        N = Np + (1 if self.class_token is not None else 0)
+        return x.new_empty((0, N, self.embed_dim), dtype=_ops.compute_dtype(x))
+
     def forward_features(self, x: torch.Tensor) -> torch.Tensor:
         """Images (B, C, H, W) -> tokens (B, N, D) entering the first block (models.py:352-361)."""
         _ops.require_cuda(x, "VisionTransformer.forward_features")
+        if x.shape[0] == 0:
+            return self._empty_tokens(x)
         with torch.cuda.device(x.device):
             x2d, B, N, D = self._features2d(x)
             return x2d[:, :D].reshape(B, N, D)
@@ -529,6 +546,8 @@ class VisionTransformer(nn.Module):
         """Tokens (B, N, D) -> blocks in order -> ``norm_final`` (models.py:408-411)."""
         _ops.require_cuda(x, "VisionTransformer.forward_heads")
         B, N, D = x.shape
+        if B * N == 0:
+            return x.new_empty((B, N, D), dtype=_ops.compute_dtype(x))
         with torch.cuda.device(x.device):
             xb, M = _as_rows(x, D)
             if xb.data_ptr() == x.data_ptr():
@@ -545,6 +564,8 @@ class VisionTransformer(nn.Module):
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         """Images (B, C, H, W) -> final-normed token embeddings (B, N, D) (models.py:413-416)."""
         _ops.require_cuda(x, "VisionTransformer.forward")
+        if x.shape[0] == 0:
+            return self._empty_tokens(x)
         with torch.cuda.device(x.device):
             x2d, B, N, D = self._run_blocks(x)
             return self._final_norm(x2d, B, N, D, x)

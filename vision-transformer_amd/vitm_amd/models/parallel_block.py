@@ -174,6 +174,8 @@ class ParallelBlock(nn.Module):
         _ops.require_cuda(x, "ParallelBlock.forward")
         B, N, C = x.shape
         assert C == self.dim, "inner dimension of x should be equal to the out_features of fused_linear_layer1"
+        if B * N == 0:
+            return x.new_empty((B, N, C), dtype=_ops.compute_dtype(x))
         with torch.cuda.device(x.device):
             xb, M = _as_rows(x, C)
             if xb.data_ptr() == x.data_ptr():

@@ -70,13 +70,16 @@ class PatchEmbed(nn.Module):
         slot = "projection_f32" if dtype == torch.float32 else "projection_bf16"
         return _ops.cached_pack(self, slot, (w, b), lambda: _ops.pack_linear(w, b, dtype=dtype))
 
-    def _tokens_into(self, x: torch.Tensor, tokens2d: torch.Tensor, cls_slot: bool) -> None:
-        """Write the projected patch tokens of image batch ``x`` into ``tokens2d`` (rows (b, n), in x's dtype)."""
+    def _check_image(self, x: torch.Tensor) -> None:
         B, C, H, W = x.shape
         assert self.image_size[0] == H, "Input tensor's height does not match the model"
         assert self.image_size[1] == W, "Input tensor's width does not match the model"
         if C != self.projection.in_channels:
             raise RuntimeError(f"expected {self.projection.in_channels} input channels, got {C}")
+
+    def _tokens_into(self, x: torch.Tensor, tokens2d: torch.Tensor, cls_slot: bool) -> None:
+        """Write the projected patch tokens of image batch ``x`` into ``tokens2d`` (rows (b, n), in x's dtype)."""
+        self._check_image(x)
         if x.dtype not in (torch.float32, torch.bfloat16):
             raise TypeError(f"unsupported image dtype {x.dtype} (bf16 or fp32)")
         _ops.patch_embed(x.contiguous(), self._packed_projection(tokens2d.dtype), tokens2d, self.patch_size,
@@ -89,6 +92,12 @@ class PatchEmbed(nn.Module):
         assert self.image_size[0] == H, "Input tensor's height does not match the model"
         assert self.image_size[1] == W, "Input tensor's width does not match the model"
         D, Np = self.projection.out_channels, self.num_patches
+        if B == 0:                                # an empty batch is an empty result, as in the reference
+            self._check_image(x)
+            if self.flatten:
+                return x.new_empty((0, Np, D), dtype=_ops.compute_dtype(x))
+            y = x.new_empty((0, D, self.grid_size[0], self.grid_size[1]), dtype=_ops.compute_dtype(x))
+            return y if self.output_fmt == "NCHW" else nchw_to(y, self.output_fmt).contiguous()
         with torch.cuda.device(x.device):
             ld = _ops.round_up(D, 8)
             tok = torch.empty((B * Np, ld), dtype=_ops.compute_dtype(x), device=x.device)
